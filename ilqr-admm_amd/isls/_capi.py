@@ -1,0 +1,380 @@
+"""ctypes binding of the C ABI declared in include/isls_hip.h.
+
+`Kernels` marshals numpy arrays or torch tensors into the argument structs of the library.  The
+product instantiates it on `csrc/libisls_hip.so` (device pointers + a HIP stream); the tests
+instantiate the very same class on the CPU oracle (`oracle/liboracle_isls.so`, host pointers, no
+stream) so that both sides are called with identical marshaling.
+
+There is NO fallback: if the HIP library is missing, `load_hip_library()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # torch is plumbing (device memory, streams); the binding itself works on numpy too
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
+ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
+SOLVE_CHOL, SOLVE_INV = 0, 1
+MODEL_LTI, MODEL_ARM3R, MODEL_CAR = 0, 1, 2
+RO_NAN_TO_1E5, RO_ACCEPT_TEST, RO_ABSOLUTE = 1, 2, 4
+PROJ_NONE, PROJ_BOX = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libisls_hip.so")
+
+
+class View(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("sb", C.c_int64), ("st", C.c_int64)]
+
+
+class GainArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("solve_mode", C.c_int32), ("_pad", C.c_int32),
+                ("A", View), ("Bm", View), ("Cxx", View), ("Cuu", View), ("Cux", View),
+                ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
+                ("status", C.c_void_p), ("active", C.c_void_p)]
+
+
+class FfArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("solve_mode", C.c_int32), ("_pad", C.c_int32),
+                ("A", View), ("Bm", View), ("c0x", View), ("c0u", View), ("Qr", View), ("Rr", View),
+                ("xhat", C.c_void_p), ("uhat", C.c_void_p),
+                ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
+                ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
+                ("k", C.c_void_p), ("active", C.c_void_p)]
+
+
+class RolloutArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("L", C.c_int32),
+                ("model", C.c_int32), ("flags", C.c_int32), ("nvia", C.c_int32),
+                ("model_par", C.c_void_p), ("model_par_sb", C.c_int64),
+                ("K", C.c_void_p), ("k", C.c_void_p), ("xhat", C.c_void_p), ("uhat", C.c_void_p),
+                ("x0", C.c_void_p), ("alphas", C.c_void_p),
+                ("Qtab", C.c_void_p), ("Qtab_sb", C.c_int64), ("ztab", C.c_void_p), ("ztab_sb", C.c_int64),
+                ("seq", C.c_void_p), ("u_std", C.c_double),
+                ("wq", View), ("wr", View),
+                ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
+                ("cost_cur", C.c_void_p), ("cost_all", C.c_void_p), ("best", C.c_void_p),
+                ("cost_new", C.c_void_p), ("x_out", C.c_void_p), ("u_out", C.c_void_p),
+                ("status", C.c_void_p), ("active", C.c_void_p)]
+
+
+class AdmmArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("proj_x", C.c_int32), ("proj_u", C.c_int32),
+                ("relax", C.c_double), ("tol_abs", C.c_double), ("tol_rel", C.c_double),
+                ("xx", C.c_void_p), ("xu", C.c_void_p),
+                ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
+                ("x_lo", View), ("x_hi", View), ("u_lo", View), ("u_hi", View),
+                ("res", C.c_void_p), ("res_prev", C.c_void_p), ("active", C.c_void_p)]
+
+
+class ExpandArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("nvia", C.c_int32), ("_pad", C.c_int32),
+                ("Qtab", C.c_void_p), ("Qtab_sb", C.c_int64), ("ztab", C.c_void_p), ("ztab_sb", C.c_int64),
+                ("seq", C.c_void_p), ("u_std", C.c_double),
+                ("Qr", View), ("Rr", View),
+                ("xhat", C.c_void_p), ("uhat", C.c_void_p),
+                ("Cxx", C.c_void_p), ("Cuu", C.c_void_p), ("c0x", C.c_void_p), ("c0u", C.c_void_p),
+                ("cost", C.c_void_p), ("active", C.c_void_p)]
+
+
+class LinearizeArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("model", C.c_int32), ("_pad", C.c_int32),
+                ("model_par", C.c_void_p), ("model_par_sb", C.c_int64),
+                ("xhat", C.c_void_p), ("uhat", C.c_void_p), ("A", C.c_void_p), ("Bm", C.c_void_p),
+                ("active", C.c_void_p)]
+
+
+class OuterArgs(C.Structure):
+    _fields_ = [("gain", GainArgs), ("ff", FfArgs), ("ro", RolloutArgs), ("admm", AdmmArgs),
+                ("J", C.c_int32), ("skip_gain", C.c_int32), ("log", C.c_void_p), ("outer_active", C.c_void_p)]
+
+
+# names every build of the library must export (checked by tests/test_capi_symbols.py)
+EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
+            ("riccati_gain", "riccati_ff", "rollout_ls", "admm_update", "expand_quadratic", "linearize",
+             "reduce_convergence", "ilqr_admm_outer")] + \
+           ["isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_read_ms"]
+
+
+class IslsError(RuntimeError):
+    pass
+
+
+def load_hip_library(path=None):
+    """dlopen the HIP library; fail loudly (no CPU fallback exists by design)."""
+    path = path or HIP_LIB_PATH
+    if not os.path.exists(path):
+        raise IslsError(f"{path} not found: build it with `python __graft_entry__.py` "
+                        f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.isls_error_string.restype = C.c_char_p
+    lib.isls_timing_read_ms.restype = C.c_double
+    lib.isls_timing_read_ms.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    return lib
+
+
+# ------------------------------------------------------------------------------------------------
+# array helpers (numpy or torch)
+# ------------------------------------------------------------------------------------------------
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        return x.data_ptr()
+    return x.ctypes.data
+
+
+def _estrides(x):
+    if _is_torch(x):
+        return tuple(x.stride())
+    return tuple(s // x.itemsize for s in x.strides)
+
+
+def _sfx(x):
+    dt = x.dtype
+    if dt in (np.float64,) or (torch is not None and dt == torch.float64):
+        return "f64"
+    if dt in (np.float32,) or (torch is not None and dt == torch.float32):
+        return "f32"
+    raise TypeError(f"unsupported dtype {dt}")
+
+
+def _dense(x, shape, name):
+    """Check a dense C-contiguous operand of exactly `shape`."""
+    if x is None:
+        return None
+    if tuple(x.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(x.shape)}")
+    contiguous = x.is_contiguous() if _is_torch(x) else x.flags["C_CONTIGUOUS"]
+    if not contiguous:
+        raise ValueError(f"{name}: must be C-contiguous")
+    return x
+
+
+def make_view(x, B, N, core, name):
+    """Strided per-(b,t) operand: trailing dims == core (contiguous), leading dims broadcast to (B,N)."""
+    if x is None:
+        return View(None, 0, 0)
+    core = tuple(core)
+    nc = len(core)
+    if tuple(x.shape[x.ndim - nc:]) != core:
+        raise ValueError(f"{name}: trailing dims {tuple(x.shape)} != {core}")
+    lead = tuple(x.shape[: x.ndim - nc])
+    if len(lead) > 2:
+        raise ValueError(f"{name}: at most two leading dims (batch, time)")
+    st = _estrides(x)
+    exp = 1
+    for d, s in zip(reversed(core), reversed(st[x.ndim - nc:])):
+        if d != 1 and s != exp:
+            raise ValueError(f"{name}: trailing dims must be contiguous")
+        exp *= d
+    lead_st = st[: x.ndim - nc]
+    if len(lead) == 0:
+        sb = s_t = 0
+    elif len(lead) == 1:            # [N, ...]: shared over the batch
+        if lead[0] not in (1, N):
+            raise ValueError(f"{name}: leading dim {lead[0]} is neither 1 nor N={N}")
+        sb, s_t = 0, (0 if lead[0] == 1 else lead_st[0])
+    else:
+        if lead[0] not in (1, B) or lead[1] not in (1, N):
+            raise ValueError(f"{name}: leading dims {lead} do not broadcast to ({B},{N})")
+        sb = 0 if lead[0] == 1 else lead_st[0]
+        s_t = 0 if lead[1] == 1 else lead_st[1]
+    return View(_ptr(x), sb, s_t)
+
+
+def _tab(x, B, core, name):
+    """Per-batch table [core] or [B, core]: returns (ptr, batch stride in elements)."""
+    core = tuple(core)
+    if tuple(x.shape) == core:
+        _dense(x, core, name)
+        return _ptr(x), 0
+    _dense(x, (B,) + core, name)
+    return _ptr(x), int(np.prod(core))
+
+
+class Kernels:
+    """Thin marshaling layer over one shared library exporting `<prefix><kernel>_<f64|f32>`."""
+
+    def __init__(self, lib, prefix="isls_", with_stream=True):
+        self.lib, self.prefix, self.with_stream = lib, prefix, with_stream
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _call(self, name, sfx, args, stream):
+        fn = getattr(self.lib, f"{self.prefix}{name}_{sfx}")
+        fn.restype = C.c_int
+        if self.with_stream:
+            rc = fn(C.byref(args), C.c_void_p(stream or 0))
+        else:
+            rc = fn(C.byref(args))
+        if rc != OK:
+            msg = {ERR_ARG: "bad argument", ERR_UNSUPPORTED: "unsupported (n,m)/model/L", ERR_LAUNCH: "launch failed"}
+            raise IslsError(f"{self.prefix}{name}_{sfx} -> {rc} ({msg.get(rc, '?')})")
+        return rc
+
+    # -- argument builders (also used to fill OuterArgs) --------------------------------------------
+    @staticmethod
+    def gain_args(A, Bm, Cxx, Cuu, K, Quu, fac, Qux, Cux=None, solve_mode=SOLVE_CHOL, status=None, active=None):
+        B, N, m, n = K.shape
+        a = GainArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode)
+        a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
+        a.Cxx, a.Cuu = make_view(Cxx, B, N, (n, n), "Cxx"), make_view(Cuu, B, N, (m, m), "Cuu")
+        a.Cux = make_view(Cux, B, N, (m, n), "Cux")
+        a.K, a.Quu = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(Quu, (B, N, m, m), "Quu"))
+        a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
+        a.status, a.active = _ptr(status), _ptr(active)
+        return a
+
+    @staticmethod
+    def ff_args(A, Bm, c0x, c0u, K, Quu, fac, Qux, k, Qr=None, Rr=None, xhat=None, uhat=None,
+                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None):
+        B, N, m, n = K.shape
+        a = FfArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode)
+        a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
+        a.c0x, a.c0u = make_view(c0x, B, N, (n,), "c0x"), make_view(c0u, B, N, (m,), "c0u")
+        a.Qr, a.Rr = make_view(Qr, B, N, (n, n), "Qr"), make_view(Rr, B, N, (m, m), "Rr")
+        if Qr is not None and (zx is None or lx is None):
+            raise ValueError("Qr given without zx/lx")
+        if Rr is not None and (zu is None or lu is None):
+            raise ValueError("Rr given without zu/lu")
+        a.xhat, a.uhat = _ptr(_dense(xhat, (B, N, n), "xhat")), _ptr(_dense(uhat, (B, N, m), "uhat"))
+        a.zx, a.lx = _ptr(_dense(zx, (B, N, n), "zx")), _ptr(_dense(lx, (B, N, n), "lx"))
+        a.zu, a.lu = _ptr(_dense(zu, (B, N, m), "zu")), _ptr(_dense(lu, (B, N, m), "lu"))
+        a.K, a.Quu = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(Quu, (B, N, m, m), "Quu"))
+        a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
+        a.k = _ptr(_dense(k, (B, N, m), "k"))
+        a.active = _ptr(active)
+        return a
+
+    @staticmethod
+    def rollout_args(model, model_par, K, k, xhat, uhat, alphas, Qtab, ztab, seq, u_std, x_out, u_out,
+                     best=None, cost_new=None, cost_all=None, x0=None, wq=None, wr=None, zx=None, lx=None,
+                     zu=None, lu=None, cost_cur=None, flags=0, status=None, active=None):
+        B, N, m, n = K.shape
+        L = int(alphas.shape[0])
+        nvia = int(Qtab.shape[-3])
+        a = RolloutArgs(B=B, N=N, n=n, m=m, L=L, model=model, flags=flags, nvia=nvia, u_std=float(u_std))
+        if model_par.ndim == 1:
+            a.model_par, a.model_par_sb = _ptr(model_par), 0
+        else:
+            _dense(model_par, (B, model_par.shape[1]), "model_par")
+            a.model_par, a.model_par_sb = _ptr(model_par), model_par.shape[1]
+        a.K, a.k = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(k, (B, N, m), "k"))
+        a.xhat, a.uhat = _ptr(_dense(xhat, (B, N, n), "xhat")), _ptr(_dense(uhat, (B, N, m), "uhat"))
+        a.x0 = _ptr(_dense(x0, (B, n), "x0"))
+        a.alphas = _ptr(alphas)
+        a.Qtab, a.Qtab_sb = _tab(Qtab, B, (nvia, n, n), "Qtab")
+        a.ztab, a.ztab_sb = _tab(ztab, B, (nvia, n), "ztab")
+        if tuple(seq.shape) != (N,):
+            raise ValueError("seq must be int32[N]")
+        a.seq = _ptr(seq)
+        a.wq, a.wr = make_view(wq, B, N, (n,), "wq"), make_view(wr, B, N, (m,), "wr")
+        if wq is not None and (zx is None or lx is None):
+            raise ValueError("wq given without zx/lx")
+        if wr is not None and (zu is None or lu is None):
+            raise ValueError("wr given without zu/lu")
+        a.zx, a.lx = _ptr(_dense(zx, (B, N, n), "zx")), _ptr(_dense(lx, (B, N, n), "lx"))
+        a.zu, a.lu = _ptr(_dense(zu, (B, N, m), "zu")), _ptr(_dense(lu, (B, N, m), "lu"))
+        if (flags & RO_ACCEPT_TEST) and cost_cur is None:
+            raise ValueError("ISLS_RO_ACCEPT_TEST needs cost_cur")
+        a.cost_cur = _ptr(_dense(cost_cur, (B,), "cost_cur"))
+        a.cost_all = _ptr(_dense(cost_all, (B, L), "cost_all"))
+        a.best, a.cost_new = _ptr(best), _ptr(_dense(cost_new, (B,), "cost_new"))
+        a.x_out, a.u_out = _ptr(_dense(x_out, (B, N, n), "x_out")), _ptr(_dense(u_out, (B, N, m), "u_out"))
+        a.status, a.active = _ptr(status), _ptr(active)
+        return a
+
+    @staticmethod
+    def admm_args(xx, xu, res, zx=None, lx=None, zu=None, lu=None, x_lo=None, x_hi=None, u_lo=None, u_hi=None,
+                  relax=1.0, tol_abs=0.0, tol_rel=0.0, res_prev=None, active=None):
+        B, N, n = xx.shape
+        m = xu.shape[2]
+        a = AdmmArgs(B=B, N=N, n=n, m=m, relax=float(relax), tol_abs=float(tol_abs), tol_rel=float(tol_rel))
+        a.proj_x = PROJ_BOX if x_lo is not None else PROJ_NONE
+        a.proj_u = PROJ_BOX if u_lo is not None else PROJ_NONE
+        a.xx, a.xu = _ptr(_dense(xx, (B, N, n), "xx")), _ptr(_dense(xu, (B, N, m), "xu"))
+        a.zx, a.lx = _ptr(_dense(zx, (B, N, n), "zx")), _ptr(_dense(lx, (B, N, n), "lx"))
+        a.zu, a.lu = _ptr(_dense(zu, (B, N, m), "zu")), _ptr(_dense(lu, (B, N, m), "lu"))
+        a.x_lo, a.x_hi = make_view(x_lo, B, N, (n,), "x_lo"), make_view(x_hi, B, N, (n,), "x_hi")
+        a.u_lo, a.u_hi = make_view(u_lo, B, N, (m,), "u_lo"), make_view(u_hi, B, N, (m,), "u_hi")
+        a.res, a.res_prev = _ptr(_dense(res, (B, 2), "res")), _ptr(_dense(res_prev, (B, 2), "res_prev"))
+        a.active = _ptr(active)
+        return a
+
+    # -- kernels -------------------------------------------------------------------------------------
+    def riccati_gain(self, *args, stream=None, **kw):
+        a = self.gain_args(*args, **kw)
+        return self._call("riccati_gain", _sfx(args[4]), a, stream)
+
+    def riccati_ff(self, *args, stream=None, **kw):
+        a = self.ff_args(*args, **kw)
+        return self._call("riccati_ff", _sfx(args[4]), a, stream)
+
+    def rollout_ls(self, *args, stream=None, **kw):
+        a = self.rollout_args(*args, **kw)
+        return self._call("rollout_ls", _sfx(args[2]), a, stream)
+
+    def admm_update(self, *args, stream=None, **kw):
+        a = self.admm_args(*args, **kw)
+        return self._call("admm_update", _sfx(args[0]), a, stream)
+
+    def expand_quadratic(self, Qtab, ztab, seq, u_std, c0x, c0u, xhat=None, uhat=None, Cxx=None, Cuu=None,
+                         Qr=None, Rr=None, cost=None, active=None, stream=None):
+        B, N, n = c0x.shape
+        m = c0u.shape[2]
+        nvia = int(Qtab.shape[-3])
+        a = ExpandArgs(B=B, N=N, n=n, m=m, nvia=nvia, u_std=float(u_std))
+        a.Qtab, a.Qtab_sb = _tab(Qtab, B, (nvia, n, n), "Qtab")
+        a.ztab, a.ztab_sb = _tab(ztab, B, (nvia, n), "ztab")
+        a.seq = _ptr(seq)
+        a.Qr, a.Rr = make_view(Qr, B, N, (n, n), "Qr"), make_view(Rr, B, N, (m, m), "Rr")
+        a.xhat, a.uhat = _ptr(_dense(xhat, (B, N, n), "xhat")), _ptr(_dense(uhat, (B, N, m), "uhat"))
+        a.Cxx, a.Cuu = _ptr(_dense(Cxx, (B, N, n, n), "Cxx")), _ptr(_dense(Cuu, (B, N, m, m), "Cuu"))
+        a.c0x, a.c0u = _ptr(_dense(c0x, (B, N, n), "c0x")), _ptr(_dense(c0u, (B, N, m), "c0u"))
+        a.cost, a.active = _ptr(_dense(cost, (B,), "cost")), _ptr(active)
+        return self._call("expand_quadratic", _sfx(c0x), a, stream)
+
+    def linearize(self, model, model_par, xhat, uhat, A, Bm, active=None, stream=None):
+        B, N, n = xhat.shape
+        m = uhat.shape[2]
+        a = LinearizeArgs(B=B, N=N, n=n, m=m, model=model)
+        if model_par.ndim == 1:
+            a.model_par, a.model_par_sb = _ptr(model_par), 0
+        else:
+            a.model_par, a.model_par_sb = _ptr(model_par), model_par.shape[1]
+        a.xhat, a.uhat = _ptr(_dense(xhat, (B, N, n), "xhat")), _ptr(_dense(uhat, (B, N, m), "uhat"))
+        a.A, a.Bm = _ptr(_dense(A, (B, N, n, n), "A")), _ptr(_dense(Bm, (B, N, n, m), "B"))
+        a.active = _ptr(active)
+        return self._call("linearize", _sfx(xhat), a, stream)
+
+    def reduce_convergence(self, cost, res, active, status, out5, stream=None):
+        fn = getattr(self.lib, f"{self.prefix}reduce_convergence_{_sfx(out5)}")
+        fn.restype = C.c_int
+        B = int(cost.shape[0]) if cost is not None else int(res.shape[0])
+        argv = [C.c_int32(B), C.c_void_p(_ptr(cost)), C.c_void_p(_ptr(res)), C.c_void_p(_ptr(active)),
+                C.c_void_p(_ptr(status)), C.c_void_p(_ptr(out5))]
+        if self.with_stream:
+            argv.append(C.c_void_p(stream or 0))
+        rc = fn(*argv)
+        if rc != OK:
+            raise IslsError(f"reduce_convergence -> {rc}")
+        return rc
+
+    def outer(self, gain, ff, ro, admm, J, sfx, skip_gain=False, log=None, outer_active=None, stream=None):
+        a = OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=int(bool(skip_gain)))
+        a.log, a.outer_active = _ptr(log), _ptr(outer_active)
+        return self._call("ilqr_admm_outer", sfx, a, stream)

@@ -1,0 +1,280 @@
+/*
+ * isls_hip.h -- C ABI of libisls_hip.so: the MI355X (gfx950) batched DP-form iLQR-ADMM hot path.
+ *
+ * The reference (chenjianxing1/iLQR-ADMM, package `isls`) is pure Python; it has NO FFI/plugin
+ * boundary.  Its hot path is the set of Python functions cited next to every entry point below;
+ * each entry point is the batched (B independent trajectories) device replacement of one of them.
+ * `INTEGRATION.md` shows the ctypes stub a maintainer of the reference would add to bind them.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (torch tensors in our host code);
+ *     the library allocates nothing, keeps no global state, and is re-entrant per stream;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: ISLS_OK or a negative ISLS_ERR_* (argument / unsupported-size / launch error);
+ *     numerical trouble is reported per trajectory in the int32 `status[B]` bit mask instead;
+ *   - dense arrays are C-contiguous row-major exactly like the reference's numpy arrays with a
+ *     leading batch axis:  K[B,N,m,n], k[B,N,m], x[B,N,n], u[B,N,m] ...
+ *   - `isls_view` = strided per-timestep operand: object (b,t) starts at p + b*sb + t*st (strides in
+ *     ELEMENTS).  sb==0 shares it over the batch, st==0 over the horizon (LTI fast path);
+ *   - `_f64` entry points read/write double, `_f32` float; struct scalars are always double;
+ *   - `active` (nullable) : trajectories with active[b]==0 are skipped entirely (frozen: converged
+ *     or failed, SURVEY section 5 "failure detection").
+ *
+ * Supported (n,m): {2,1} {4,2} {6,3} {9,3} (the reference notebooks' systems); others ->
+ * ISLS_ERR_UNSUPPORTED.  1 <= L <= 64.
+ */
+#ifndef ISLS_HIP_H
+#define ISLS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISLS_VERSION 100
+
+#define ISLS_OK 0
+#define ISLS_ERR_ARG (-1)
+#define ISLS_ERR_UNSUPPORTED (-2)
+#define ISLS_ERR_LAUNCH (-3)
+
+/* status[b] bits */
+#define ISLS_ST_NOT_PD 1     /* Quu not positive definite (reference: LinAlgError from dposv, isls/isls.py:296) */
+#define ISLS_ST_NAN_COST 2   /* a line-search candidate produced a NaN cost (isls/isls.py:362) */
+#define ISLS_ST_LS_REJECT 4  /* no candidate improved the cost (fp_success False, isls/isls.py:365-372) */
+
+/* Quu solve: iLQR path uses Cholesky (isls/isls.py:296), SLS.solve_dp an explicit inverse (isls/sls.py:149-151) */
+#define ISLS_SOLVE_CHOL 0
+#define ISLS_SOLVE_INV 1
+
+/* built-in forward models f(x,u) (reference: user callbacks in the notebooks) */
+#define ISLS_MODEL_LTI 0    /* x+ = A x + B u ; par = [A(n*n), B(n*m)]            (isls/sls_base.py:49-53)       */
+#define ISLS_MODEL_ARM3R 1  /* planar 3R arm, n=9 m=3 ; par = [dt]                 (3DoF notebooks cells 9-10)    */
+#define ISLS_MODEL_CAR 2    /* car-simple, n=4 m=2 ; par = [dt]                    (Car notebooks cell 6)         */
+
+/* rollout flags */
+#define ISLS_RO_NAN_TO_1E5 1   /* costs[isnan] = 1e5            (iterate_once_dp only, isls/isls.py:362)          */
+#define ISLS_RO_ACCEPT_TEST 2  /* accept iff cost_best < cost_cur (isls/isls.py:365-369); else nominal is kept    */
+#define ISLS_RO_ABSOLUTE 4     /* u = K x + k (xhat=uhat=0, alpha forced to 1): SLSBase.get_trajectory_dp         */
+
+/* projections (z-step of ADMM) */
+#define ISLS_PROJ_NONE 0
+#define ISLS_PROJ_BOX 1        /* np.clip(x, lo, hi)   isls/projections.py:7-11 ; bounds per (t, dim), +-inf = free */
+
+typedef struct isls_view {
+    const void *p;
+    int64_t sb, st;
+} isls_view;
+
+/* ---------------------------------------------------------------------------------------------
+ * Riccati backward pass, gain part.
+ * Replaces iSLS.backward_pass_DP (isls/isls.py:229-308; K and the factors that do not depend on the
+ * linear cost terms) and SLS.solve_dp(return_Qs=True) (isls/sls.py:85-166).
+ *   V_{N-1} = Cxx[N-1];  for t = N-2..0:
+ *     Qxx = Cxx + A'VA, Qux = Cux + B'VA, Quu = Cuu + B'VB
+ *     K_t = -Quu^{-1} Qux   (Cholesky U'U, or explicit inverse in ISLS_SOLVE_INV mode)
+ *     V   = Qxx + K'Quu K + Qux'K + K'Qux                         (no symmetrisation, isls.py:300-301)
+ * Outputs (dense): K[B,N,m,n] (K[N-1]=0), Quu[B,N,m,m], Qux[B,N,m,n] and
+ *   fac[B,N,m,m]: CHOL mode: upper factor U with the DIAGONAL STORED AS 1/U_ii (strict lower = 0);
+ *                 INV  mode: Quu^{-1} (the reference's Quu_inv_log).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_gain_args {
+    int32_t B, N, n, m;
+    int32_t solve_mode;
+    int32_t _pad;
+    isls_view A;    /* [.,.,n,n] */
+    isls_view Bm;   /* [.,.,n,m] */
+    isls_view Cxx;  /* [.,.,n,n] */
+    isls_view Cuu;  /* [.,.,m,m] */
+    isls_view Cux;  /* [.,.,m,n] ; p==NULL -> 0 */
+    void *K, *Quu, *fac, *Qux;
+    int32_t *status;       /* [B] OR-ed in */
+    const int32_t *active; /* nullable */
+} isls_gain_args;
+
+int isls_riccati_gain_f64(const isls_gain_args *a, void *stream);
+int isls_riccati_gain_f32(const isls_gain_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Riccati backward pass, feed-forward part (once per ADMM iteration).
+ * Replaces the v/k recursion of iSLS.backward_pass_DP (isls/isls.py:285-302) and SLS.solve_dp_ff
+ * (isls/sls.py:168-202) with the cached K, Quu, fac, Qux of the gain pass:
+ *   cx_t = c0x_t + 2 Qr_t (xhat_t - (zx_t - lx_t)),  cu_t = c0u_t + 2 Rr_t (uhat_t - (zu_t - lu_t))
+ *   v_{N-1} = cx_{N-1};  for t = N-2..0:
+ *     qx = cx + A'v, qu = cu + B'v, k_t = -Quu^{-1} qu, v = qx + K'qu + K'Quu k + Qux'k
+ * (the ADMM regulariser of isls/sls.py:132-137 and of O2).  xhat/uhat NULL -> 0 (absolute
+ * coordinates, SLS path).  Qr.p / Rr.p NULL -> that term (and zx,lx / zu,lu) is unused.
+ * Output k[B,N,m] (k[N-1]=0).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_ff_args {
+    int32_t B, N, n, m;
+    int32_t solve_mode;
+    int32_t _pad;
+    isls_view A, Bm;
+    isls_view c0x; /* [.,.,n] */
+    isls_view c0u; /* [.,.,m] */
+    isls_view Qr;  /* [.,.,n,n] nullable */
+    isls_view Rr;  /* [.,.,m,m] nullable */
+    const void *xhat, *uhat;        /* [B,N,n], [B,N,m] nullable */
+    const void *zx, *lx, *zu, *lu;  /* ADMM consensus / scaled dual, dense */
+    const void *K, *Quu, *fac, *Qux;
+    void *k;
+    const int32_t *active;
+} isls_ff_args;
+
+int isls_riccati_ff_f64(const isls_ff_args *a, void *stream);
+int isls_riccati_ff_f32(const isls_ff_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Forward line-search rollout + cost + arg-min + winner trajectory.
+ * Replaces iSLS.rollout_DP (isls/isls.py:310-334), the candidate costs / arg-min / acceptance of
+ * iSLS.iterate_once_dp (isls.py:357-369), the quadratic via-point cost SLSBase.compute_cost
+ * (isls/sls_base.py:25-44, no 1/2) and the augmented-Lagrangian terms of the ilqr_admm line search
+ * (isls/isls.py:471-476, `(dx*dx)@Qr` precedence => weights are the ROW SUMS of Qr: wq, wr).
+ *   candidate l: x_0 = xhat_0 ; u_t = K_t (x_t - xhat_t) + alpha_l k_t + uhat_t ; x_{t+1} = f(x_t,u_t)
+ *   cost_l  = sum_t (x_t-z_t)'Q_t(x_t-z_t) + u_std |u_t|^2           (Q_t=Qtab[seq[t]], z_t=ztab[seq[t]])
+ *   aug_l   = cost_l + sum_t wq_t.(x_t-(zx_t-lx_t))^2 + wr_t.(u_t-(zu_t-lu_t))^2
+ *   best = first arg-min of aug ; x_out,u_out = trajectory of `best` ; cost_new = cost_best (plain)
+ * Outputs: cost_all[B,L] (aug, nullable), best[B], cost_new[B], x_out[B,N,n], u_out[B,N,m].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_rollout_args {
+    int32_t B, N, n, m, L;
+    int32_t model;
+    int32_t flags;
+    int32_t nvia;
+    const void *model_par;
+    int64_t model_par_sb;           /* 0 = shared */
+    const void *K, *k, *xhat, *uhat;
+    const void *x0;                 /* [B,n] nullable: default xhat[:,0] */
+    const void *alphas;             /* [L] */
+    const void *Qtab;               /* [.,nvia,n,n] */
+    int64_t Qtab_sb;
+    const void *ztab;               /* [.,nvia,n] */
+    int64_t ztab_sb;
+    const int32_t *seq;             /* [N] */
+    double u_std;
+    isls_view wq;                   /* [.,.,n] nullable */
+    isls_view wr;                   /* [.,.,m] nullable */
+    const void *zx, *lx, *zu, *lu;
+    const void *cost_cur;           /* [B], ISLS_RO_ACCEPT_TEST only */
+    void *cost_all;
+    int32_t *best;
+    void *cost_new;
+    void *x_out, *u_out;
+    int32_t *status;
+    const int32_t *active;
+} isls_rollout_args;
+
+int isls_rollout_ls_f64(const isls_rollout_args *a, void *stream);
+int isls_rollout_ls_f32(const isls_rollout_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ADMM z/dual update with projection, residuals and the two stop rules.
+ * Replaces the body of ADMM() after the x-step (isls/admm.py:43-85) with project_x/project_u given
+ * as descriptors (box: isls/projections.py:7-11):
+ *   z_prev = z ; z = Proj(relax*x + (1-relax)*z + lmb) ; r = x - z ; lmb += r
+ *   prim = |r_x| + |r_u| ; dual = |z_x - z_prev_x| + |z_u - z_prev_u|        (unscaled 2-norms)
+ *   stop  if prim<tol_abs and dual<tol_abs, else if both relative changes (vs res_prev, +1e-30) < tol_rel
+ * res[B,2] receives (prim,dual); res_prev[B,2] is read then overwritten with them (init 1e6, admm.py:25-26);
+ * active[b] is cleared when a stop rule fires (nullable => no stop rule evaluated).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_admm_args {
+    int32_t B, N, n, m;
+    int32_t proj_x, proj_u;
+    double relax, tol_abs, tol_rel;
+    const void *xx, *xu;
+    void *zx, *lx, *zu, *lu;   /* a NULL z pointer disables that block (project_x / project_u False) */
+    isls_view x_lo, x_hi;      /* [.,.,n] */
+    isls_view u_lo, u_hi;      /* [.,.,m] */
+    void *res, *res_prev;
+    int32_t *active;
+} isls_admm_args;
+
+int isls_admm_update_f64(const isls_admm_args *a, void *stream);
+int isls_admm_update_f32(const isls_admm_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Quadratic via-point cost expansion about the nominal (the `Cts is None` branch of
+ * backward_pass_DP, isls/isls.py:263-271, written out as arrays, plus the ADMM regulariser):
+ *   Cxx[b,t] = 2 Q_t (+ 2 Qr_t) ; Cuu[b,t] = 2 u_std I (+ 2 Rr_t)
+ *   c0x[b,t] = 2 Q_t (xhat_t - z_t) ; c0u[b,t] = 2 u_std uhat_t ; cost[b] = compute_cost(xhat,uhat)
+ * Cxx/Cuu may be NULL (skip).  xhat/uhat NULL -> 0 (absolute coordinates).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_expand_args {
+    int32_t B, N, n, m;
+    int32_t nvia, _pad;
+    const void *Qtab; int64_t Qtab_sb;
+    const void *ztab; int64_t ztab_sb;
+    const int32_t *seq;
+    double u_std;
+    isls_view Qr, Rr;               /* nullable */
+    const void *xhat, *uhat;
+    void *Cxx, *Cuu;                /* [B,N,n,n], [B,N,m,m] nullable */
+    void *c0x, *c0u;                /* [B,N,n], [B,N,m] */
+    void *cost;                     /* [B] nullable */
+    const int32_t *active;
+} isls_expand_args;
+
+int isls_expand_quadratic_f64(const isls_expand_args *a, void *stream);
+int isls_expand_quadratic_f32(const isls_expand_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Linearisation of the built-in models along the nominal: the user's get_AB(xhat,uhat) callback
+ * (isls/isls.py:61-66,95; notebooks).  A[B,N,n,n], B[B,N,n,m] dense outputs.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_linearize_args {
+    int32_t B, N, n, m;
+    int32_t model, _pad;
+    const void *model_par; int64_t model_par_sb;
+    const void *xhat, *uhat;
+    void *A, *Bm;
+    const int32_t *active;
+} isls_linearize_args;
+
+int isls_linearize_f64(const isls_linearize_args *a, void *stream);
+int isls_linearize_f32(const isls_linearize_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convergence reduction over the local batch shard: out[5] = { sum cost, max prim, max dual,
+ * #active, #status!=0 } -- the 40-byte payload of the per-iteration RCCL all-reduce.
+ * Batched analogue of the scalar tests at isls/isls.py:125-132,493-499 and isls/admm.py:72-85.
+ * ------------------------------------------------------------------------------------------- */
+int isls_reduce_convergence_f64(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                const int32_t *status, void *out5, void *stream);
+int isls_reduce_convergence_f32(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                const int32_t *status, void *out5, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One outer DP-form iLQR-ADMM iteration enqueued as a whole (SURVEY 3.3 with the dense solve
+ * replaced by the Riccati pass): gain -> J x [ ff -> rollout/line-search -> ADMM update ].
+ * The sub-structs are used as given; between inner iterations nothing is exchanged with the host.
+ * `log` (nullable) receives res per inner iteration: log[j,B,2].  `admm_active` is set from
+ * `outer_active` (nullable => all ones) before the first inner iteration.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_outer_args {
+    isls_gain_args gain;
+    isls_ff_args ff;
+    isls_rollout_args ro;
+    isls_admm_args admm;
+    int32_t J;
+    int32_t skip_gain;          /* reuse the cached factors (is_dynamics_linear && is_cost_quadratic) */
+    void *log;
+    const int32_t *outer_active;
+} isls_outer_args;
+
+int isls_ilqr_admm_outer_f64(const isls_outer_args *a, void *stream);
+int isls_ilqr_admm_outer_f32(const isls_outer_args *a, void *stream);
+
+int isls_version(void);
+const char *isls_error_string(int code);
+/* name + duration bookkeeping used by bench.py: records hipEvents around the launches of one
+ * kernel family on `stream`. kind: 0 gain, 1 ff, 2 rollout, 3 admm.  Returns ms of the last
+ * completed timed launch set, or <0 if timing is disabled. */
+int isls_timing_enable(int on);
+double isls_timing_read_ms(int kind, int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISLS_HIP_H */

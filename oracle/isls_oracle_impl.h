@@ -1,0 +1,613 @@
+/*
+ * isls_oracle_impl.h -- body of the CPU oracle, included twice by isls_oracle.c (REAL = double / float).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a scalar, per-trajectory C restatement of the reference's
+ * algorithm (chenjianxing1/iLQR-ADMM, python package `isls`) for the hot path of SURVEY.md section 8.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it; the product
+ * (libisls_hip.so + ilqr-admm_amd/isls) never links, imports or falls back to it.
+ *
+ * Pinned: tests/test_oracle_golden.py checks every function below against golden vectors produced
+ * by running the reference itself in the build container (tests/golden/make_golden.py).
+ *
+ * Every function cites the reference lines it restates.  Operation order follows the reference
+ * (association of matrix products, order of the sums); LAPACK calls (dposv, dgesv) are replaced
+ * by the unblocked textbook algorithms LAPACK itself uses at these sizes.
+ */
+
+#define MAXN 16
+#define MAXM 8
+
+/* object (b,t) of a strided view */
+#define VIEW(v, b, t) (((const REAL *)(v).p) + (int64_t)(b) * (v).sb + (int64_t)(t) * (v).st)
+
+/* ---- tiny dense helpers (row-major) ---------------------------------------------------------- */
+/* C[p x r] = A^T[p x q] * B[q x r] where A is stored q x p */
+static void FN(matTmul)(const REAL *A, const REAL *B, REAL *C, int q, int p, int r)
+{
+    for (int i = 0; i < p; ++i)
+        for (int j = 0; j < r; ++j) {
+            REAL s = 0;
+            for (int k = 0; k < q; ++k) s += A[k * p + i] * B[k * r + j];
+            C[i * r + j] = s;
+        }
+}
+/* C[p x r] = A[p x q] * B[q x r] */
+static void FN(matmul)(const REAL *A, const REAL *B, REAL *C, int p, int q, int r)
+{
+    for (int i = 0; i < p; ++i)
+        for (int j = 0; j < r; ++j) {
+            REAL s = 0;
+            for (int k = 0; k < q; ++k) s += A[i * q + k] * B[k * r + j];
+            C[i * r + j] = s;
+        }
+}
+
+/* Upper Cholesky A = U^T U, unblocked (LAPACK dpotf2 'U' order).  Returns 0 or 1 if not PD. */
+static int FN(chol_upper)(const REAL *A, REAL *U, int m)
+{
+    for (int i = 0; i < m * m; ++i) U[i] = 0;
+    for (int j = 0; j < m; ++j) {
+        REAL ajj = A[j * m + j];
+        for (int k = 0; k < j; ++k) ajj -= U[k * m + j] * U[k * m + j];
+        if (!(ajj > 0)) return 1;
+        ajj = SQRT(ajj);
+        U[j * m + j] = ajj;
+        for (int c = j + 1; c < m; ++c) {
+            REAL s = A[j * m + c];
+            for (int k = 0; k < j; ++k) s -= U[k * m + j] * U[k * m + c];
+            U[j * m + c] = s / ajj;
+        }
+    }
+    return 0;
+}
+/* solve U^T U x = b (dpotrs 'U': forward with U^T, backward with U) */
+static void FN(chol_solve)(const REAL *U, const REAL *b, REAL *x, int m)
+{
+    REAL y[MAXM];
+    for (int i = 0; i < m; ++i) {
+        REAL s = b[i];
+        for (int k = 0; k < i; ++k) s -= U[k * m + i] * y[k];
+        y[i] = s / U[i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        REAL s = y[i];
+        for (int k = i + 1; k < m; ++k) s -= U[i * m + k] * x[k];
+        x[i] = s / U[i * m + i];
+    }
+}
+/* inverse by LU with partial pivoting applied to the identity (numpy.linalg.inv = dgesv(A, I)) */
+static int FN(inv_lu)(const REAL *A, REAL *Ainv, int m)
+{
+    REAL LU[MAXM * MAXM];
+    int piv[MAXM];
+    for (int i = 0; i < m * m; ++i) LU[i] = A[i];
+    for (int j = 0; j < m; ++j) {
+        int p = j;
+        REAL best = FABS(LU[j * m + j]);
+        for (int i = j + 1; i < m; ++i)
+            if (FABS(LU[i * m + j]) > best) { best = FABS(LU[i * m + j]); p = i; }
+        piv[j] = p;
+        if (best == 0) return 1;
+        if (p != j)
+            for (int c = 0; c < m; ++c) { REAL tmp = LU[j * m + c]; LU[j * m + c] = LU[p * m + c]; LU[p * m + c] = tmp; }
+        for (int i = j + 1; i < m; ++i) {
+            LU[i * m + j] /= LU[j * m + j];
+            for (int c = j + 1; c < m; ++c) LU[i * m + c] -= LU[i * m + j] * LU[j * m + c];
+        }
+    }
+    for (int col = 0; col < m; ++col) {
+        REAL e[MAXM];
+        for (int i = 0; i < m; ++i) e[i] = (i == col) ? 1 : 0;
+        for (int j = 0; j < m; ++j)
+            if (piv[j] != j) { REAL tmp = e[j]; e[j] = e[piv[j]]; e[piv[j]] = tmp; }
+        for (int i = 0; i < m; ++i)
+            for (int k = 0; k < i; ++k) e[i] -= LU[i * m + k] * e[k];
+        for (int i = m - 1; i >= 0; --i) {
+            for (int k = i + 1; k < m; ++k) e[i] -= LU[i * m + k] * e[k];
+            e[i] /= LU[i * m + i];
+        }
+        for (int i = 0; i < m; ++i) Ainv[i * m + col] = e[i];
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Gain pass.  isls/isls.py:245-308 (CHOL) and isls/sls.py:98-162 (INV), K-dependent part.
+ * ------------------------------------------------------------------------------------------- */
+int FN(oracle_riccati_gain)(const isls_gain_args *a)
+{
+    const int B = a->B, N = a->N, n = a->n, m = a->m;
+    if (B < 0 || N < 1 || n < 1 || m < 1 || n > MAXN || m > MAXM) return ISLS_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        if (a->active && !a->active[b]) continue;
+        REAL *K = (REAL *)a->K + (int64_t)b * N * m * n;
+        REAL *Quu_o = (REAL *)a->Quu + (int64_t)b * N * m * m;
+        REAL *fac_o = (REAL *)a->fac + (int64_t)b * N * m * m;
+        REAL *Qux_o = (REAL *)a->Qux + (int64_t)b * N * m * n;
+        REAL V[MAXN * MAXN], AtV[MAXN * MAXN], BtV[MAXM * MAXN];
+        REAL Qxx[MAXN * MAXN], Qux[MAXM * MAXN], Quu[MAXM * MAXM];
+        REAL U[MAXM * MAXM], Kt[MAXM * MAXN], KtQuu[MAXN * MAXM], T1[MAXN * MAXN], T2[MAXN * MAXN], T3[MAXN * MAXN];
+        /* terminal: K[N-1]=0 (isls.py:245), V = Cxx[N-1] (isls.py:251,257) */
+        for (int i = 0; i < m * n; ++i) { K[(N - 1) * m * n + i] = 0; Qux_o[(N - 1) * m * n + i] = 0; }
+        for (int i = 0; i < m * m; ++i) { Quu_o[(N - 1) * m * m + i] = 0; fac_o[(N - 1) * m * m + i] = 0; }
+        {
+            const REAL *C = VIEW(a->Cxx, b, N - 1);
+            for (int i = 0; i < n * n; ++i) V[i] = C[i];
+        }
+        int bad = 0;
+        for (int t = N - 2; t >= 0; --t) {
+            const REAL *A = VIEW(a->A, b, t), *Bm = VIEW(a->Bm, b, t);
+            const REAL *Cxx = VIEW(a->Cxx, b, t), *Cuu = VIEW(a->Cuu, b, t);
+            const REAL *Cux = a->Cux.p ? VIEW(a->Cux, b, t) : 0;
+            /* Qxx = Cxx + (A'V)A ; Qux = Cux + (B'V)A ; Quu = Cuu + (B'V)B   (isls.py:288-290) */
+            FN(matTmul)(A, V, AtV, n, n, n);
+            FN(matTmul)(Bm, V, BtV, n, m, n);
+            FN(matmul)(AtV, A, Qxx, n, n, n);
+            FN(matmul)(BtV, A, Qux, m, n, n);
+            FN(matmul)(BtV, Bm, Quu, m, n, m);
+            for (int i = 0; i < n * n; ++i) Qxx[i] = Cxx[i] + Qxx[i];
+            for (int i = 0; i < m * n; ++i) Qux[i] = (Cux ? Cux[i] : (REAL)0) + Qux[i];
+            for (int i = 0; i < m * m; ++i) Quu[i] = Cuu[i] + Quu[i];
+            REAL *fac = fac_o + (int64_t)t * m * m;
+            if (a->solve_mode == ISLS_SOLVE_CHOL) {
+                /* sol = -solve(Quu, [Qux qu], assume_a="pos")  (isls.py:296-298) */
+                if (FN(chol_upper)(Quu, U, m)) { bad = 1; break; }
+                for (int j = 0; j < n; ++j) {
+                    REAL rhs[MAXM], x[MAXM];
+                    for (int r = 0; r < m; ++r) rhs[r] = Qux[r * n + j];
+                    FN(chol_solve)(U, rhs, x, m);
+                    for (int r = 0; r < m; ++r) Kt[r * n + j] = -x[r];
+                }
+                for (int i = 0; i < m; ++i)
+                    for (int j = 0; j < m; ++j) fac[i * m + j] = (i == j) ? (REAL)1 / U[i * m + i] : U[i * m + j];
+            } else {
+                /* Quu_inv = inv(Quu); Kt = -Quu_inv.dot(Qux)  (sls.py:149-150) */
+                if (FN(inv_lu)(Quu, fac, m)) { bad = 1; break; }
+                FN(matmul)(fac, Qux, Kt, m, m, n);
+                for (int i = 0; i < m * n; ++i) Kt[i] = -Kt[i];
+            }
+            /* V update */
+            FN(matTmul)(Kt, Quu, KtQuu, m, n, m);  /* K'Quu   n x m */
+            FN(matmul)(KtQuu, Kt, T1, n, m, n);    /* (K'Quu)K       */
+            FN(matTmul)(Qux, Kt, T2, m, n, n);     /* Qux'K          */
+            FN(matTmul)(Kt, Qux, T3, m, n, n);     /* K'Qux          */
+            if (a->solve_mode == ISLS_SOLVE_CHOL)   /* isls.py:300: Qxx + K'QuuK + Qux'K + K'Qux */
+                for (int i = 0; i < n * n; ++i) V[i] = ((Qxx[i] + T1[i]) + T2[i]) + T3[i];
+            else                                    /* sls.py:153:  Qxx + Qux'K + K'Qux + K'QuuK */
+                for (int i = 0; i < n * n; ++i) V[i] = ((Qxx[i] + T2[i]) + T3[i]) + T1[i];
+            for (int i = 0; i < m * n; ++i) { K[(int64_t)t * m * n + i] = Kt[i]; Qux_o[(int64_t)t * m * n + i] = Qux[i]; }
+            for (int i = 0; i < m * m; ++i) Quu_o[(int64_t)t * m * m + i] = Quu[i];
+        }
+        if (bad && a->status) a->status[b] |= ISLS_ST_NOT_PD;
+    }
+    return ISLS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Feed-forward pass.  isls/isls.py:252-302 (v,k part; dposv re-factorises Quu every call, so does
+ * this oracle) and isls/sls.py:168-202 (INV: uses the cached Quu_inv = fac).
+ * ------------------------------------------------------------------------------------------- */
+static void FN(reg_grad)(const isls_ff_args *a, int b, int t, REAL *cx, REAL *cu)
+{
+    const int N = a->N, n = a->n, m = a->m;
+    const REAL *c0x = VIEW(a->c0x, b, t), *c0u = VIEW(a->c0u, b, t);
+    for (int i = 0; i < n; ++i) cx[i] = c0x[i];
+    for (int i = 0; i < m; ++i) cu[i] = c0u[i];
+    if (a->Qr.p) {
+        const REAL *Qr = VIEW(a->Qr, b, t);
+        const REAL *xh = a->xhat ? (const REAL *)a->xhat + ((int64_t)b * N + t) * n : 0;
+        const REAL *z = (const REAL *)a->zx + ((int64_t)b * N + t) * n, *l = (const REAL *)a->lx + ((int64_t)b * N + t) * n;
+        REAL d[MAXN];
+        for (int j = 0; j < n; ++j) d[j] = (xh ? xh[j] : (REAL)0) - (z[j] - l[j]);
+        for (int i = 0; i < n; ++i) {
+            REAL s = 0;
+            for (int j = 0; j < n; ++j) s += Qr[i * n + j] * d[j];
+            cx[i] += 2 * s;
+        }
+    }
+    if (a->Rr.p) {
+        const REAL *Rr = VIEW(a->Rr, b, t);
+        const REAL *uh = a->uhat ? (const REAL *)a->uhat + ((int64_t)b * N + t) * m : 0;
+        const REAL *z = (const REAL *)a->zu + ((int64_t)b * N + t) * m, *l = (const REAL *)a->lu + ((int64_t)b * N + t) * m;
+        REAL d[MAXM];
+        for (int j = 0; j < m; ++j) d[j] = (uh ? uh[j] : (REAL)0) - (z[j] - l[j]);
+        for (int i = 0; i < m; ++i) {
+            REAL s = 0;
+            for (int j = 0; j < m; ++j) s += Rr[i * m + j] * d[j];
+            cu[i] += 2 * s;
+        }
+    }
+}
+
+int FN(oracle_riccati_ff)(const isls_ff_args *a)
+{
+    const int B = a->B, N = a->N, n = a->n, m = a->m;
+    if (B < 0 || N < 1 || n < 1 || m < 1 || n > MAXN || m > MAXM) return ISLS_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        if (a->active && !a->active[b]) continue;
+        REAL *kout = (REAL *)a->k + (int64_t)b * N * m;
+        REAL v[MAXN], cx[MAXN], cu[MAXM], qx[MAXN], qu[MAXM], kt[MAXM], U[MAXM * MAXM], w[MAXM];
+        for (int i = 0; i < m; ++i) kout[(N - 1) * m + i] = 0;
+        FN(reg_grad)(a, b, N - 1, v, cu);
+        for (int t = N - 2; t >= 0; --t) {
+            const REAL *A = VIEW(a->A, b, t), *Bm = VIEW(a->Bm, b, t);
+            const REAL *K = (const REAL *)a->K + ((int64_t)b * N + t) * m * n;
+            const REAL *Quu = (const REAL *)a->Quu + ((int64_t)b * N + t) * m * m;
+            const REAL *fac = (const REAL *)a->fac + ((int64_t)b * N + t) * m * m;
+            const REAL *Qux = (const REAL *)a->Qux + ((int64_t)b * N + t) * m * n;
+            FN(reg_grad)(a, b, t, cx, cu);
+            for (int i = 0; i < n; ++i) { REAL s = 0; for (int k = 0; k < n; ++k) s += A[k * n + i] * v[k]; qx[i] = cx[i] + s; }
+            for (int i = 0; i < m; ++i) { REAL s = 0; for (int k = 0; k < n; ++k) s += Bm[k * m + i] * v[k]; qu[i] = cu[i] + s; }
+            if (a->solve_mode == ISLS_SOLVE_CHOL) {
+                if (FN(chol_upper)(Quu, U, m)) break;
+                FN(chol_solve)(U, qu, kt, m);
+                for (int i = 0; i < m; ++i) kt[i] = -kt[i];
+            } else {
+                for (int i = 0; i < m; ++i) { REAL s = 0; for (int j = 0; j < m; ++j) s += fac[i * m + j] * qu[j]; kt[i] = -s; }
+            }
+            /* w = (K'Quu) k is evaluated as K'(row) after KtQuu, like Kt.T.dot(Quu).dot(kt) */
+            for (int i = 0; i < n; ++i) {
+                REAL t_kqu = 0, t_kquuk = 0, t_quxk = 0;
+                for (int r = 0; r < m; ++r) t_kqu += K[r * n + i] * qu[r];
+                for (int c = 0; c < m; ++c) {
+                    REAL kq = 0;
+                    for (int r = 0; r < m; ++r) kq += K[r * n + i] * Quu[r * m + c];
+                    w[c] = kq;
+                }
+                for (int c = 0; c < m; ++c) t_kquuk += w[c] * kt[c];
+                for (int r = 0; r < m; ++r) t_quxk += Qux[r * n + i] * kt[r];
+                if (a->solve_mode == ISLS_SOLVE_CHOL)  /* isls.py:302 */
+                    v[i] = ((qx[i] + t_kqu) + t_kquuk) + t_quxk;
+                else                                    /* sls.py:200 */
+                    v[i] = ((qx[i] + t_quxk) + t_kqu) + t_kquuk;
+            }
+            for (int i = 0; i < m; ++i) kout[(int64_t)t * m + i] = kt[i];
+        }
+    }
+    return ISLS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Built-in forward models (specs: SURVEY Appendix A; notebooks).
+ * ------------------------------------------------------------------------------------------- */
+static REAL FN(pymod)(REAL a, REAL b) /* numpy `%` on floats: fmod + sign fix */
+{
+    REAL r = FMOD(a, b);
+    if (r != 0 && ((b < 0) != (r < 0))) r += b;
+    return r;
+}
+
+static void FN(model_step)(int model, const REAL *par, int n, int m, const REAL *x, const REAL *u, REAL *xn)
+{
+    if (model == ISLS_MODEL_LTI) { /* x.dot(A.T) + u.dot(B.T), isls/sls_base.py:49-53 */
+        const REAL *A = par, *Bm = par + n * n;
+        for (int i = 0; i < n; ++i) {
+            REAL s = 0, r = 0;
+            for (int j = 0; j < n; ++j) s += A[i * n + j] * x[j];
+            for (int j = 0; j < m; ++j) r += Bm[i * m + j] * u[j];
+            xn[i] = s + r;
+        }
+    } else if (model == ISLS_MODEL_ARM3R) { /* 3DoF notebook cell 9 + closed-form FK */
+        const REAL dt = par[0];
+        REAL c = 0, ex = 0, ey = 0;
+        for (int j = 0; j < 3; ++j) {
+            xn[j] = x[j] + x[3 + j] * dt + (REAL)0.5 * u[j] * (dt * dt);
+            xn[3 + j] = x[3 + j] + u[j] * dt;
+        }
+        for (int j = 0; j < 3; ++j) { c += xn[j]; ex += COS(c); ey += SIN(c); }
+        xn[6] = ex; xn[7] = ey; xn[8] = 0;
+    } else { /* car-simple, Car notebooks cell 6 */
+        const REAL dt = par[0];
+        xn[0] = x[0] + dt * x[3] * COS(x[2]);
+        xn[1] = x[1] + dt * x[3] * SIN(x[2]);
+        xn[2] = FN(pymod)(x[2] + dt * x[3] * u[0], (REAL)(2 * 3.14159265358979323846));
+        xn[3] = x[3] + dt * u[1];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Line-search rollout.  isls/isls.py:310-334 (rollout_DP), 357-369 (candidates, NaN rule, arg-min,
+ * acceptance), isls/sls_base.py:25-44 (cost), isls/isls.py:471-477 (AL terms, no acceptance test).
+ * ------------------------------------------------------------------------------------------- */
+static void FN(rollout_one)(const isls_rollout_args *a, int b, REAL alpha, REAL *xs, REAL *us, REAL *cost, REAL *aug)
+{
+    const int N = a->N, n = a->n, m = a->m;
+    const REAL *K = (const REAL *)a->K + (int64_t)b * N * m * n, *k = (const REAL *)a->k + (int64_t)b * N * m;
+    const REAL *xh = a->xhat ? (const REAL *)a->xhat + (int64_t)b * N * n : 0;
+    const REAL *uh = a->uhat ? (const REAL *)a->uhat + (int64_t)b * N * m : 0;
+    const REAL *par = (const REAL *)a->model_par + (int64_t)b * a->model_par_sb;
+    const REAL *Qtab = (const REAL *)a->Qtab + (int64_t)b * a->Qtab_sb;
+    const REAL *ztab = (const REAL *)a->ztab + (int64_t)b * a->ztab_sb;
+    const int absolute = (a->flags & ISLS_RO_ABSOLUTE) != 0;
+    REAL x[MAXN], xn[MAXN], u[MAXM];
+    REAL cst = 0, ag = 0;
+    if (a->x0) for (int i = 0; i < n; ++i) x[i] = ((const REAL *)a->x0)[(int64_t)b * n + i];
+    else for (int i = 0; i < n; ++i) x[i] = xh[i];
+    for (int t = 0; t < N; ++t) {
+        for (int r = 0; r < m; ++r) { /* u = dx @ K.T + k[:,i] + u_nom[i]  (isls.py:329) */
+            REAL s = 0;
+            for (int j = 0; j < n; ++j) s += ((absolute || !xh) ? x[j] : x[j] - xh[t * n + j]) * K[((int64_t)t * m + r) * n + j];
+            u[r] = (s + alpha * k[t * m + r]) + ((absolute || !uh) ? (REAL)0 : uh[t * m + r]);
+        }
+        if (xs) { for (int i = 0; i < n; ++i) xs[t * n + i] = x[i]; for (int i = 0; i < m; ++i) us[t * m + i] = u[i]; }
+        if (cost) {
+            const REAL *Q = Qtab + (int64_t)a->seq[t] * n * n, *z = ztab + (int64_t)a->seq[t] * n;
+            REAL d[MAXN];
+            for (int i = 0; i < n; ++i) d[i] = x[i] - z[i];
+            for (int i = 0; i < n; ++i) { REAL s = 0; for (int j = 0; j < n; ++j) s += Q[i * n + j] * d[j]; cst += d[i] * s; }
+        }
+        if (aug && a->wq.p) {
+            const REAL *w = VIEW(a->wq, b, t);
+            const REAL *z = (const REAL *)a->zx + ((int64_t)b * N + t) * n, *l = (const REAL *)a->lx + ((int64_t)b * N + t) * n;
+            for (int i = 0; i < n; ++i) { REAL d = x[i] - (z[i] - l[i]); ag += (d * d) * w[i]; }
+        }
+        if (aug && a->wr.p) {
+            const REAL *w = VIEW(a->wr, b, t);
+            const REAL *z = (const REAL *)a->zu + ((int64_t)b * N + t) * m, *l = (const REAL *)a->lu + ((int64_t)b * N + t) * m;
+            for (int i = 0; i < m; ++i) { REAL d = u[i] - (z[i] - l[i]); ag += (d * d) * w[i]; }
+        }
+        FN(model_step)(a->model, par, n, m, x, u, xn);   /* x = f(x,u), isls.py:332 */
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+    }
+    /* *cost is the STATE part only; the caller adds the control part from the stored controls so
+     * that the order is the reference's: sum over x first, then += sum over u (sls_base.py:33-39). */
+    if (cost) *cost = cst;
+    if (aug) *aug = ag;
+}
+
+int FN(oracle_rollout_ls)(const isls_rollout_args *a)
+{
+    const int B = a->B, N = a->N, n = a->n, m = a->m, L = a->L;
+    if (B < 0 || N < 1 || n < 1 || m < 1 || n > MAXN || m > MAXM || L < 1 || L > 64) return ISLS_ERR_ARG;
+    int rc = ISLS_OK;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        if (a->active && !a->active[b]) continue;
+        REAL *xs = (REAL *)malloc(sizeof(REAL) * (size_t)N * (n + m));
+        REAL *us = xs + (size_t)N * n;
+        REAL costs[64], augs[64];
+        const REAL ustd = (REAL)a->u_std;
+        int nan_seen = 0;
+        for (int l = 0; l < L; ++l) {
+            REAL alpha = (a->flags & ISLS_RO_ABSOLUTE) ? (REAL)1 : ((const REAL *)a->alphas)[l];
+            REAL cst, ag;
+            FN(rollout_one)(a, b, alpha, xs, us, &cst, &ag);
+            REAL cu = 0;
+            for (int i = 0; i < N * m; ++i) cu += us[i] * (ustd * us[i]);
+            costs[l] = cst + cu;
+            augs[l] = costs[l] + ag;
+            if (augs[l] != augs[l]) {
+                nan_seen = 1;
+                if (a->flags & ISLS_RO_NAN_TO_1E5) { augs[l] = (REAL)1e5; costs[l] = (REAL)1e5; }
+            }
+        }
+        int ind = 0; /* np.argmin: first minimum; NaN propagates as minimum in numpy */
+        for (int l = 1; l < L; ++l) {
+            if (augs[ind] != augs[ind]) break;
+            if (augs[l] != augs[l] || augs[l] < augs[ind]) ind = l;
+        }
+        if (a->cost_all) for (int l = 0; l < L; ++l) ((REAL *)a->cost_all)[(int64_t)b * L + l] = augs[l];
+        int accept = 1;
+        if (a->flags & ISLS_RO_ACCEPT_TEST) accept = (costs[ind] - ((const REAL *)a->cost_cur)[b]) < 0;
+        REAL *xo = (REAL *)a->x_out + (int64_t)b * N * n, *uo = (REAL *)a->u_out + (int64_t)b * N * m;
+        if (accept) {
+            REAL alpha = (a->flags & ISLS_RO_ABSOLUTE) ? (REAL)1 : ((const REAL *)a->alphas)[ind];
+            FN(rollout_one)(a, b, alpha, xo, uo, 0, 0);
+            if (a->cost_new) ((REAL *)a->cost_new)[b] = costs[ind];
+        } else {
+            const REAL *xh = (const REAL *)a->xhat + (int64_t)b * N * n, *uh = (const REAL *)a->uhat + (int64_t)b * N * m;
+            for (int i = 0; i < N * n; ++i) xo[i] = xh[i];
+            for (int i = 0; i < N * m; ++i) uo[i] = uh[i];
+            if (a->cost_new) ((REAL *)a->cost_new)[b] = ((const REAL *)a->cost_cur)[b];
+        }
+        if (a->best) a->best[b] = ind;
+        if (a->status) a->status[b] |= (nan_seen ? ISLS_ST_NAN_COST : 0) | (accept ? 0 : ISLS_ST_LS_REJECT);
+        free(xs);
+    }
+    return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * ADMM update.  isls/admm.py:43-85, box projection isls/projections.py:7-11.
+ * ------------------------------------------------------------------------------------------- */
+static void FN(admm_block)(int N, int d, int proj, REAL relax, const REAL *x, REAL *z, REAL *l,
+                           const isls_view *lo, const isls_view *hi, int b, REAL *prim2, REAL *dual2)
+{
+    REAL p2 = 0, d2 = 0;
+    for (int t = 0; t < N; ++t) {
+        const REAL *lo_t = proj == ISLS_PROJ_BOX ? VIEW(*lo, b, t) : 0, *hi_t = proj == ISLS_PROJ_BOX ? VIEW(*hi, b, t) : 0;
+        for (int i = 0; i < d; ++i) {
+            const int e = t * d + i;
+            REAL zp = z[e];
+            REAL zz = relax * x[e] + (1 - relax) * zp;   /* admm.py:48 */
+            REAL arg = zz + l[e];
+            REAL zn = arg;
+            if (proj == ISLS_PROJ_BOX) { zn = arg < lo_t[i] ? lo_t[i] : arg; zn = zn > hi_t[i] ? hi_t[i] : zn; } /* np.clip */
+            REAL r = x[e] - zn;                            /* admm.py:51 */
+            l[e] += r;                                     /* admm.py:52 */
+            z[e] = zn;
+            p2 += r * r;
+            d2 += (zn - zp) * (zn - zp);
+        }
+    }
+    *prim2 = p2; *dual2 = d2;
+}
+
+int FN(oracle_admm_update)(const isls_admm_args *a)
+{
+    const int B = a->B, N = a->N, n = a->n, m = a->m;
+    if (B < 0 || N < 1 || n < 1 || m < 1) return ISLS_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        if (a->active && !a->active[b]) continue;
+        REAL prim = 0, dual = 0, p2, d2;
+        if (a->zx) {
+            FN(admm_block)(N, n, a->proj_x, (REAL)a->relax, (const REAL *)a->xx + (int64_t)b * N * n,
+                           (REAL *)a->zx + (int64_t)b * N * n, (REAL *)a->lx + (int64_t)b * N * n, &a->x_lo, &a->x_hi, b, &p2, &d2);
+            prim += SQRT(p2); dual += SQRT(d2);
+        }
+        if (a->zu) {
+            FN(admm_block)(N, m, a->proj_u, (REAL)a->relax, (const REAL *)a->xu + (int64_t)b * N * m,
+                           (REAL *)a->zu + (int64_t)b * N * m, (REAL *)a->lu + (int64_t)b * N * m, &a->u_lo, &a->u_hi, b, &p2, &d2);
+            prim += SQRT(p2); dual += SQRT(d2);
+        }
+        REAL *res = (REAL *)a->res + (int64_t)b * 2;
+        REAL *prev = a->res_prev ? (REAL *)a->res_prev + (int64_t)b * 2 : 0;
+        if (a->active && prev) {
+            int stop = 0;
+            if (prim < (REAL)a->tol_abs && dual < (REAL)a->tol_abs) stop = 1;            /* admm.py:72 */
+            else {
+                REAL pc = FABS(prev[0] - prim) / (prev[0] + (REAL)1e-30);               /* admm.py:78-80 */
+                REAL dc = FABS(prev[1] - dual) / (prev[1] + (REAL)1e-30);
+                if (pc < (REAL)a->tol_rel && dc < (REAL)a->tol_rel) stop = 1;
+            }
+            if (stop) a->active[b] = 0;
+        }
+        res[0] = prim; res[1] = dual;
+        if (prev) { prev[0] = prim; prev[1] = dual; }
+    }
+    return ISLS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Quadratic expansion.  isls/isls.py:263-271 (Cts None branch) + regulariser (isls/sls.py:132-137);
+ * cost: isls/sls_base.py:25-44.
+ * ------------------------------------------------------------------------------------------- */
+int FN(oracle_expand_quadratic)(const isls_expand_args *a)
+{
+    const int B = a->B, N = a->N, n = a->n, m = a->m;
+    if (B < 0 || N < 1 || n < 1 || m < 1 || n > MAXN || m > MAXM) return ISLS_ERR_ARG;
+    const REAL ustd = (REAL)a->u_std;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        if (a->active && !a->active[b]) continue;
+        const REAL *Qtab = (const REAL *)a->Qtab + (int64_t)b * a->Qtab_sb, *ztab = (const REAL *)a->ztab + (int64_t)b * a->ztab_sb;
+        REAL cx_sum = 0, cu_sum = 0;
+        for (int t = 0; t < N; ++t) {
+            const REAL *Q = Qtab + (int64_t)a->seq[t] * n * n, *z = ztab + (int64_t)a->seq[t] * n;
+            const REAL *xh = a->xhat ? (const REAL *)a->xhat + ((int64_t)b * N + t) * n : 0;
+            const REAL *uh = a->uhat ? (const REAL *)a->uhat + ((int64_t)b * N + t) * m : 0;
+            REAL d[MAXN];
+            for (int i = 0; i < n; ++i) d[i] = (xh ? xh[i] : (REAL)0) - z[i];
+            REAL *c0x = (REAL *)a->c0x + ((int64_t)b * N + t) * n, *c0u = (REAL *)a->c0u + ((int64_t)b * N + t) * m;
+            for (int i = 0; i < n; ++i) {
+                REAL s = 0;
+                for (int j = 0; j < n; ++j) s += Q[i * n + j] * d[j];
+                c0x[i] = 2 * s;
+                cx_sum += d[i] * s;
+            }
+            for (int i = 0; i < m; ++i) {
+                REAL uu = uh ? uh[i] : (REAL)0;
+                c0u[i] = 2 * (ustd * uu);
+                cu_sum += uu * (ustd * uu);
+            }
+            if (a->Cxx) {
+                REAL *C = (REAL *)a->Cxx + ((int64_t)b * N + t) * n * n;
+                const REAL *Qr = a->Qr.p ? VIEW(a->Qr, b, t) : 0;
+                for (int i = 0; i < n * n; ++i) C[i] = 2 * Q[i] + (Qr ? 2 * Qr[i] : (REAL)0);
+            }
+            if (a->Cuu) {
+                REAL *C = (REAL *)a->Cuu + ((int64_t)b * N + t) * m * m;
+                const REAL *Rr = a->Rr.p ? VIEW(a->Rr, b, t) : 0;
+                for (int i = 0; i < m; ++i)
+                    for (int j = 0; j < m; ++j) C[i * m + j] = ((i == j) ? 2 * ustd : (REAL)0) + (Rr ? 2 * Rr[i * m + j] : (REAL)0);
+            }
+        }
+        if (a->cost) ((REAL *)a->cost)[b] = cx_sum + cu_sum;
+    }
+    return ISLS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Linearisation of the built-in models (the notebooks' get_AB callbacks).
+ * ------------------------------------------------------------------------------------------- */
+int FN(oracle_linearize)(const isls_linearize_args *a)
+{
+    const int B = a->B, N = a->N, n = a->n, m = a->m;
+    if (B < 0 || N < 1) return ISLS_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        if (a->active && !a->active[b]) continue;
+        const REAL *par = (const REAL *)a->model_par + (int64_t)b * a->model_par_sb;
+        for (int t = 0; t < N; ++t) {
+            REAL *A = (REAL *)a->A + ((int64_t)b * N + t) * n * n, *Bm = (REAL *)a->Bm + ((int64_t)b * N + t) * n * m;
+            const REAL *x = (const REAL *)a->xhat + ((int64_t)b * N + t) * n, *u = (const REAL *)a->uhat + ((int64_t)b * N + t) * m;
+            for (int i = 0; i < n * n; ++i) A[i] = 0;
+            for (int i = 0; i < n * m; ++i) Bm[i] = 0;
+            if (a->model == ISLS_MODEL_LTI) {
+                for (int i = 0; i < n * n; ++i) A[i] = par[i];
+                for (int i = 0; i < n * m; ++i) Bm[i] = par[n * n + i];
+            } else if (a->model == ISLS_MODEL_ARM3R) {
+                const REAL dt = par[0];
+                REAL q[3], c = 0, sn[3], cs[3];
+                for (int j = 0; j < 3; ++j) {
+                    q[j] = x[j] + x[3 + j] * dt + (REAL)0.5 * u[j] * (dt * dt);
+                    c += q[j]; sn[j] = SIN(c); cs[j] = COS(c);
+                }
+                for (int j = 0; j < 3; ++j) {
+                    A[j * 9 + j] = 1; A[j * 9 + 3 + j] = dt; A[(3 + j) * 9 + 3 + j] = 1;
+                    Bm[j * 3 + j] = (REAL)0.5 * (dt * dt); /* dt^2/2! */
+                    Bm[(3 + j) * 3 + j] = dt;
+                }
+                for (int j = 0; j < 3; ++j) {
+                    REAL j0 = 0, j1 = 0; /* J[0,j] = -sum_{i>=j} sin c_i, J[1,j] = sum_{i>=j} cos c_i */
+                    for (int i = j; i < 3; ++i) { j0 += sn[i]; j1 += cs[i]; }
+                    j0 = -j0;
+                    A[6 * 9 + j] = j0; A[7 * 9 + j] = j1;
+                    A[6 * 9 + 3 + j] = j0 * dt; A[7 * 9 + 3 + j] = j1 * dt;
+                    Bm[6 * 3 + j] = ((REAL)0.5 * j0) * (dt * dt); Bm[7 * 3 + j] = ((REAL)0.5 * j1) * (dt * dt);
+                }
+            } else {
+                const REAL dt = par[0];
+                for (int i = 0; i < 4; ++i) A[i * 4 + i] = 1;
+                A[0 * 4 + 2] = -dt * x[3] * SIN(x[2]);
+                A[1 * 4 + 2] = dt * x[3] * COS(x[2]);
+                A[0 * 4 + 3] = dt * COS(x[2]);
+                A[1 * 4 + 3] = dt * SIN(x[2]);
+                A[2 * 4 + 3] = dt * u[0];
+                Bm[2 * 2 + 0] = dt * x[3];
+                Bm[3 * 2 + 1] = dt;
+            }
+        }
+    }
+    return ISLS_OK;
+}
+
+int FN(oracle_reduce_convergence)(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                  const int32_t *status, void *out5)
+{
+    REAL *o = (REAL *)out5;
+    REAL cs = 0, pm = 0, dm = 0, na = 0, nf = 0;
+    for (int b = 0; b < B; ++b) {
+        if (cost) cs += ((const REAL *)cost)[b];
+        if (res) { REAL p = ((const REAL *)res)[2 * b], d = ((const REAL *)res)[2 * b + 1]; if (p > pm) pm = p; if (d > dm) dm = d; }
+        if (active) na += active[b] ? 1 : 0; else na += 1;
+        if (status) nf += status[b] ? 1 : 0;
+    }
+    o[0] = cs; o[1] = pm; o[2] = dm; o[3] = na; o[4] = nf;
+    return ISLS_OK;
+}
+
+/* One outer iteration: gain -> J x [ff -> rollout -> update]  (SURVEY 3.3 / 8d metric definition). */
+int FN(oracle_ilqr_admm_outer)(const isls_outer_args *a)
+{
+    int rc;
+    const int B = a->gain.B;
+    if (a->admm.active)
+        for (int b = 0; b < B; ++b) a->admm.active[b] = a->outer_active ? a->outer_active[b] : 1;
+    if (!a->skip_gain && (rc = FN(oracle_riccati_gain)(&a->gain)) != ISLS_OK) return rc;
+    for (int j = 0; j < a->J; ++j) {
+        if ((rc = FN(oracle_riccati_ff)(&a->ff)) != ISLS_OK) return rc;
+        if ((rc = FN(oracle_rollout_ls)(&a->ro)) != ISLS_OK) return rc;
+        isls_admm_args ad = a->admm;
+        if ((rc = FN(oracle_admm_update)(&ad)) != ISLS_OK) return rc;
+        if (a->log) memcpy((REAL *)a->log + (int64_t)j * B * 2, ad.res, sizeof(REAL) * (size_t)B * 2);
+    }
+    return ISLS_OK;
+}
+
+#undef VIEW
+#undef MAXN
+#undef MAXM

@@ -1,0 +1,551 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
+        python3 tests/golden/make_golden.py
+
+The reference (`/root/reference/isls`, pure python/numpy/scipy) is imported, never copied; only its
+*outputs* on seeded inputs are stored (small .npz files).  Nothing here runs on the GPU box.
+
+What the reference runs unmodified: all of `SLS`, `ADMM`, `projections`,
+`iSLS.backward_pass_DP / rollout_DP / iterate_once_dp / solve(method='dp', get_Cs=...)`.
+HEAD's `iSLS` quadratic-cost path has API drift (no `compute_cost`, `C`/`D` undefined, `ADMM(threshold=)`),
+so `RefISLS` below is the documented compatibility shim: a subclass that binds the missing names to
+the reference's OWN implementations (`SLSBase.compute_cost`, `Sw`, `Su`) -- no numerics of ours.
+
+"O2" = DP-form iLQR-ADMM composed ONLY of reference functions (regularised Cts/cts ->
+`backward_pass_DP` -> `rollout_DP` -> `cost_function` + AL terms -> argmin, as `f_argmin` of the
+reference's `ADMM()`), with the outer-loop semantics of `iSLS.ilqr_admm` (isls/isls.py:379-501).
+The generator asserts that O2 reproduces the reference's own batch-form `ilqr_admm` (shimmed).
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+import isls as ref                                    # noqa: E402  (the REFERENCE package)
+import isls.isls as ref_isls_mod                      # noqa: E402
+from isls.admm import ADMM as REF_ADMM                # noqa: E402
+from isls.sls_base import SLSBase as RefSLSBase       # noqa: E402
+refproj = sys.modules["isls.projections"]             # `isls.projections` the attribute is shadowed by a dict
+
+assert ref.__file__.startswith("/root/reference/"), ref.__file__
+
+_spec = importlib.util.spec_from_file_location(
+    "isls_problems", os.path.join(REPO, "ilqr-admm_amd", "isls_problems.py"))
+P = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(P)
+
+
+class RefISLS(ref.iSLS):
+    """Compatibility shim: bind names HEAD lost to the reference's own code."""
+    compute_cost = RefSLSBase.compute_cost
+    C = property(lambda self: self.Sw)
+    D = property(lambda self: self.Su)
+
+    def set_cost_variables(self, zs, Qs, seq, u_std):
+        return self.set_quadratic_cost(zs, Qs, seq, u_std)
+
+
+def _admm_threshold_shim(*a, threshold=None, **kw):
+    if threshold is not None:
+        kw["tol"] = threshold
+    return REF_ADMM(*a, **kw)
+
+
+ref_isls_mod.ADMM = _admm_threshold_shim             # `ilqr_admm` passes threshold= (isls.py:485)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KiB, keys={len(arrays)}")
+
+
+# ---------------------------------------------------------------------------------------------
+# G1/G2: LQT on the 1-D double integrator (unmodified SLS)
+# ---------------------------------------------------------------------------------------------
+def gen_di1d():
+    out = {}
+    for tag, N in (("n100", 100), ("n50", 50)):
+        c = P.config1(N)
+        sls = ref.SLS(2, 1, N)
+        sls.AB = [c["A"], c["B"]]
+        sls.set_quadratic_cost(c["zs"], c["Qs"], c["seq"], c["u_std"])
+        x_opt, u_opt = sls.solve(c["x0"], method="batch")
+        out[f"{tag}_batch_x"] = x_opt
+        out[f"{tag}_batch_u"] = u_opt
+        if N == 100:   # pins recorded in the notebook (control bounds.ipynb:154-156)
+            assert np.max(u_opt) == 6.06051888764695, np.max(u_opt)
+            assert x_opt[-1, 0] == 0.9999876316133441
+        K, k = sls.solve_dp()
+        out[f"{tag}_dp_K"], out[f"{tag}_dp_k"] = K, k
+        Qr, Rr = sls.compute_Rr_Qr(rho_x=None, rho_u=c["rho_u"], dp=True)
+        rng = np.random.default_rng(11)
+        ur = rng.standard_normal(N)
+        K2, k2, Quu, Quu_inv, Qux = sls.solve_dp(Rr=Rr, Qr=Qr, xr=np.zeros(2 * N), ur=ur, return_Qs=True)
+        out[f"{tag}_reg_ur"] = ur
+        out[f"{tag}_reg_K"], out[f"{tag}_reg_k"] = K2, k2
+        out[f"{tag}_reg_Quu"], out[f"{tag}_reg_Quu_inv"], out[f"{tag}_reg_Qux"] = Quu, Quu_inv, Qux
+        ur2 = rng.standard_normal(N)
+        out[f"{tag}_ff_ur"] = ur2
+        out[f"{tag}_ff_k"] = sls.solve_dp_ff(K2, Quu, Qux, Quu_inv, Qr=Qr, Rr=Rr, ur=ur2, xr=np.zeros(2 * N))
+        # state-regularised variant (Qr) as well
+        Qr3, Rr3 = sls.compute_Rr_Qr(rho_x=0.5, rho_u=c["rho_u"], dp=True)
+        xr3 = rng.standard_normal(2 * N)
+        K3, k3, Quu3, Quu_inv3, Qux3 = sls.solve_dp(Rr=Rr3, Qr=Qr3, xr=xr3, ur=ur, return_Qs=True)
+        out[f"{tag}_regx_xr"] = xr3
+        out[f"{tag}_regx_K"], out[f"{tag}_regx_k"] = K3, k3
+        proj = lambda u: refproj.project_bound(u, c["u_lo"], c["u_hi"])   # noqa: E731
+        xa, ua, Ka, ka, logs = sls.ADMM_LQT_DP(c["x0"], project_u=proj, max_iter=500, rho_u=c["rho_u"],
+                                               tol=c["tol"], verbose=False, log=True)
+        out[f"{tag}_admm_dp_x"], out[f"{tag}_admm_dp_u"] = xa, ua
+        out[f"{tag}_admm_dp_K"], out[f"{tag}_admm_dp_k"] = Ka, ka
+        out[f"{tag}_admm_dp_logs"] = np.stack(logs)
+        out[f"{tag}_admm_dp_cost"] = np.array(sls.compute_cost(xa, ua))
+        # fixed-iteration variant for kernel-level traces (no early stop: tol=0)
+        xa, ua, Ka, ka, logs = sls.ADMM_LQT_DP(c["x0"], project_u=proj, max_iter=8, rho_u=c["rho_u"],
+                                               tol=0.0, verbose=False, log=True)
+        out[f"{tag}_admm8_x"], out[f"{tag}_admm8_u"], out[f"{tag}_admm8_k"] = xa, ua, ka
+        out[f"{tag}_admm8_logs"] = np.stack(logs)
+        xb, ub, logb = sls.ADMM_LQT_Batch(x0=c["x0"], project_u=proj, max_iter=100, rho_u=1e-2, tol=1e-4,
+                                          verbose=False, log=True)
+        out[f"{tag}_admm_batch_u"] = ub
+        out[f"{tag}_admm_batch_logs"] = np.stack(logb)
+        if N == 100:   # control bounds.ipynb:204-207
+            assert len(logb) == 20 and np.max(ub) == 5.000018035934772, (len(logb), np.max(ub))
+    save("g1_di1d_lqt.npz", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# O2: DP-form iLQR-ADMM from reference functions
+# ---------------------------------------------------------------------------------------------
+def make_ref_isls(cfg, b):
+    """Reference iSLS object for trajectory b of a batched config."""
+    n, m, N = cfg["n"], cfg["m"], cfg["N"]
+    f, get_AB = P.model_callbacks(cfg)
+    obj = RefISLS(n, m, N)
+    obj.forward_model = f
+    zs = cfg["zs"][b] if cfg["zs"].ndim == 3 else cfg["zs"]
+    obj.set_cost_variables(zs, cfg["Qs"], cfg["seq"], cfg["u_std"])
+    x_nom, u_nom = P.initial_nominal(cfg, b)
+    obj.reset()
+    obj.nominal_values = x_nom, u_nom
+    return obj, get_AB
+
+
+def expansions(obj, Qr, Rr, rx, ru):
+    """Regularised quadratic-cost expansion in delta coordinates."""
+    n, m, N = obj.x_dim, obj.u_dim, obj.N
+    Cts = np.zeros((N, n + m, n + m))
+    cts = np.zeros((N, n + m))
+    for t in range(N):
+        Q = obj.Qs[obj.seq[t]]
+        Cts[t, :n, :n] = 2 * Q
+        Cts[t, n:, n:] = 2 * obj.Rt
+        cts[t, :n] = 2 * Q.dot(obj.x_nom[t] - obj.zs[obj.seq[t]])
+        cts[t, n:] = 2 * obj.Rt.dot(obj.u_nom[t])
+        if Qr is not None:
+            Cts[t, :n, :n] += 2 * Qr[t]
+            cts[t, :n] += 2 * Qr[t].dot(obj.x_nom[t] - rx[t])
+        if Rr is not None:
+            Cts[t, n:, n:] += 2 * Rr[t]
+            cts[t, n:] += 2 * Rr[t].dot(obj.u_nom[t] - ru[t])
+    return Cts, cts
+
+
+def o2_ilqr_admm(obj, get_AB, project_x, project_u, rho_x, rho_u, max_iter, L, J, relax, tol, trace):
+    """Outer loop with the semantics of iSLS.ilqr_admm (isls/isls.py:420-499), DP inner solve."""
+    n, m, N = obj.x_dim, obj.u_dim, obj.N
+    Qr, Rr = obj.compute_Rr_Qr(rho_x=rho_x, rho_u=rho_u, dp=True)
+    if not project_x:
+        Qr = None
+    if not project_u:
+        Rr = None
+    import scipy.linalg
+    Qr_bd = scipy.linalg.block_diag(*Qr) if Qr is not None else None
+    Rr_bd = scipy.linalg.block_diag(*Rr) if Rr is not None else None
+    alphas = obj.alphas[:L]
+    z_x_init = z_u_init = None
+    n_outer = 0
+    for j in range(max_iter):
+        prev_cost = np.copy(obj.cost)
+        obj.A, obj.B = get_AB(obj.x_nom, obj.u_nom)
+        inner = dict(K=None, k=[], xx=[], xu=[], regx=[], regu=[], cost_aug=[], ind=[])
+
+        def f_argmin(x, u):
+            rx = x.reshape(N, n) if x is not None else None
+            ru = u.reshape(N, m) if u is not None else None
+            Cts, cts = expansions(obj, Qr, Rr, rx, ru)
+            K, k = obj.backward_pass_DP(Cts=Cts, cts=cts)
+            k_new = k[None] * alphas[:, None, None]
+            x_noms, u_noms = obj.rollout_DP(K, k_new)
+            costs = obj.cost_function(x_noms, u_noms)
+            costs = np.atleast_1d(costs).astype(float)
+            if Qr is not None:
+                dx = x_noms.reshape(-1, N * n) - x
+                costs += np.sum(dx * dx @ Qr_bd, axis=-1)
+            if Rr is not None:
+                du = u_noms.reshape(-1, N * m) - u
+                costs += np.sum(du * du @ Rr_bd, axis=-1)
+            ind = np.argmin(costs)
+            inner["K"] = K
+            inner["k"].append(k)
+            inner["xx"].append(x_noms[ind].copy())
+            inner["xu"].append(u_noms[ind].copy())
+            inner["regx"].append(np.zeros((N, n)) if rx is None else rx.copy())
+            inner["regu"].append(np.zeros((N, m)) if ru is None else ru.copy())
+            inner["cost_aug"].append(costs.copy())
+            inner["ind"].append(ind)
+            return x_noms[ind].flatten(), u_noms[ind].flatten()
+
+        admm = REF_ADMM(n * N, m * N, f_argmin, project_x=project_x, project_u=project_u,
+                        z_x_init=z_x_init, z_u_init=z_u_init, lmb_x_init=None, lmb_u_init=None,
+                        return_lmb=1, alpha=relax, max_iter=J, tol=tol, verbose=False, log=True)
+        obj.nominal_values = admm[0].reshape(N, -1), admm[1].reshape(N, -1)
+        lmb_x, lmb_u, z_x, z_u, logs = admm[2], admm[3], admm[4], admm[5], admm[6]
+        z_x_init, z_u_init = z_x, z_u
+        n_outer += 1
+        trace.append(dict(inner=inner, logs=np.stack(logs), cost=float(obj.cost),
+                          z_x=None if z_x is None else z_x.copy(), z_u=None if z_u is None else z_u.copy(),
+                          lmb_x=None if lmb_x is None else lmb_x.copy(),
+                          lmb_u=None if lmb_u is None else lmb_u.copy(),
+                          x_nom=obj.x_nom.copy(), u_nom=obj.u_nom.copy()))
+        if np.abs(obj.cost - prev_cost) < 1e-3:
+            break
+        if np.abs(np.mean(obj.cost_log[-4:]) - np.mean(obj.cost_log[-8:-4])) < 1e-3:
+            break
+    return n_outer
+
+
+def pack_trace(prefix, traces, n, m, N, J, out):
+    """traces: list over trajectories of list over outer its. Ragged inner counts padded with NaN."""
+    Bt = len(traces)
+    n_outer = max(len(t) for t in traces)
+    shp = (Bt, n_outer)
+    K = np.full(shp + (N, m, n), np.nan)
+    k = np.full(shp + (J, N, m), np.nan)
+    xx = np.full(shp + (J, N, n), np.nan)
+    xu = np.full(shp + (J, N, m), np.nan)
+    regx = np.full(shp + (J, N, n), np.nan)
+    regu = np.full(shp + (J, N, m), np.nan)
+    logs = np.full(shp + (J, 2), np.nan)
+    cost = np.full(shp, np.nan)
+    zx = np.full(shp + (N, n), np.nan)
+    zu = np.full(shp + (N, m), np.nan)
+    lx = np.full(shp + (N, n), np.nan)
+    lu = np.full(shp + (N, m), np.nan)
+    n_inner = np.zeros(shp, dtype=np.int32)
+    outer_count = np.array([len(t) for t in traces], dtype=np.int32)
+    for b, tr in enumerate(traces):
+        for o, it in enumerate(tr):
+            ji = len(it["inner"]["k"])
+            n_inner[b, o] = ji
+            K[b, o] = it["inner"]["K"]
+            k[b, o, :ji] = np.stack(it["inner"]["k"])
+            xx[b, o, :ji] = np.stack(it["inner"]["xx"])
+            xu[b, o, :ji] = np.stack(it["inner"]["xu"])
+            regx[b, o, :ji] = np.stack(it["inner"]["regx"])
+            regu[b, o, :ji] = np.stack(it["inner"]["regu"])
+            logs[b, o, :ji] = it["logs"]
+            cost[b, o] = it["cost"]
+            if it["z_x"] is not None:
+                zx[b, o] = it["z_x"].reshape(N, n)
+                lx[b, o] = it["lmb_x"].reshape(N, n)
+            if it["z_u"] is not None:
+                zu[b, o] = it["z_u"].reshape(N, m)
+                lu[b, o] = it["lmb_u"].reshape(N, m)
+    out.update({f"{prefix}_K": K, f"{prefix}_k": k, f"{prefix}_xx": xx, f"{prefix}_xu": xu,
+                f"{prefix}_regx": regx, f"{prefix}_regu": regu, f"{prefix}_logs": logs,
+                f"{prefix}_cost": cost, f"{prefix}_zx": zx, f"{prefix}_zu": zu, f"{prefix}_lx": lx,
+                f"{prefix}_lu": lu, f"{prefix}_n_inner": n_inner, f"{prefix}_n_outer": outer_count})
+
+
+def trace_sensitivity(cfg, bsel, run_o2, keys=("K", "k", "xx", "xu", "logs", "cost")):
+    """Conditioning probe: re-run the REFERENCE O2 trace with the initial controls perturbed by one
+    part in 1e15 and record, per quantity, max|delta| / max(1,|ref|_max).  A restatement that differs
+    from the reference only by floating-point summation order cannot be expected to agree better
+    than this; the parity tests use max(1e-10, 10 x sensitivity) as their tolerance."""
+    base, pert = {}, {}
+    for tag, store, eps in (("base", base, 0.0), ("pert", pert, 1e-15)):
+        c = dict(cfg)
+        c["u0"] = cfg["u0"] * (1.0 + eps) + eps
+        traces = [run_o2(c, b) for b in bsel]
+        pack_trace("s", traces, c["n"], c["m"], c["N"], max(len(t["inner"]["k"]) for tr in traces for t in tr), store)
+    sens = {}
+    for k in keys:
+        a, b = base[f"s_{k}"], pert[f"s_{k}"]
+        ok = ~(np.isnan(a) | np.isnan(b))
+        sens[k] = float(np.max(np.abs(a[ok] - b[ok])) / max(1.0, float(np.max(np.abs(a[ok])))))
+    return sens
+
+
+def box_projectors(cfg):
+    N, n, m = cfg["N"], cfg["n"], cfg["m"]
+    proj_u = lambda u: refproj.project_bound(u, cfg["u_lo"], cfg["u_hi"])      # noqa: E731
+    proj_x = False
+    if "x_lo" in cfg:
+        lo, hi = cfg["x_lo"].reshape(-1), cfg["x_hi"].reshape(-1)
+        proj_x = lambda x: refproj.project_bound(x, lo, hi)                    # noqa: E731
+    return proj_x, proj_u
+
+
+def gen_di3d():
+    out = {}
+    Bt, L, J = 2, 20, 5
+    cfg = P.config2(batch=4, N=100, seed=0)
+    n, m, N = cfg["n"], cfg["m"], cfg["N"]
+    out["cfg_batch"], out["cfg_seed"] = np.array(4), np.array(0)
+    # --- kernel-level vectors at the initial nominal -----------------------------------------
+    Kq, kq, Kc, kc, costs, xsel, usel, it_once = [], [], [], [], [], [], [], []
+    rxs, rus = [], []
+    rng = np.random.default_rng(5)
+    for b in range(Bt):
+        obj, get_AB = make_ref_isls(cfg, b)
+        obj.A, obj.B = get_AB(obj.x_nom, obj.u_nom)
+        K, k = obj.backward_pass_DP()                      # quadratic branch (Cts=None)
+        Kq.append(K), kq.append(k)
+        rx = obj.x_nom + 0.1 * rng.standard_normal((N, n))
+        ru = obj.u_nom + 0.1 * rng.standard_normal((N, m))
+        Qr, Rr = obj.compute_Rr_Qr(rho_x=0.3, rho_u=1e-2, dp=True)
+        Cts, cts = expansions(obj, Qr, Rr, rx, ru)
+        K2, k2 = obj.backward_pass_DP(Cts=Cts, cts=cts)    # general branch, regularised
+        Kc.append(K2), kc.append(k2), rxs.append(rx), rus.append(ru)
+        k_new = k[None] * obj.alphas[:L, None, None]
+        x_noms, u_noms = obj.rollout_DP(K, k_new)
+        costs.append(obj.cost_function(x_noms, u_noms))
+        xsel.append(x_noms[[0, 7, 19]]), usel.append(u_noms[[0, 7, 19]])
+        ok, _, _ = obj.iterate_once_dp(max_line_search=L)
+        it_once.append(np.concatenate([[float(ok), obj.cost], obj.x_nom.ravel(), obj.u_nom.ravel()]))
+    out.update(bp_quad_K=np.stack(Kq), bp_quad_k=np.stack(kq), bp_reg_K=np.stack(Kc), bp_reg_k=np.stack(kc),
+               bp_reg_rx=np.stack(rxs), bp_reg_ru=np.stack(rus), ro_costs=np.stack(costs),
+               ro_x_sel=np.stack(xsel), ro_u_sel=np.stack(usel), iter_once=np.stack(it_once))
+    # --- unconstrained iLQR (iterate_once_dp loop with the stop rules of isls.py:125-132) -----
+    logs = []
+    for b in range(Bt):
+        obj, get_AB = make_ref_isls(cfg, b)
+        for i in range(10):
+            obj.A, obj.B = get_AB(obj.x_nom, obj.u_nom)
+            ok, _, _ = obj.iterate_once_dp(max_line_search=L)
+            if np.abs(np.diff(obj.cost_log[-2:])) < 1e-5 or not ok:
+                break
+        logs.append(np.pad(np.array(obj.cost_log, dtype=float), (0, 12 - len(obj.cost_log)), constant_values=np.nan))
+    out["ilqr_cost_log"] = np.stack(logs)
+    # --- O2 traces ----------------------------------------------------------------------------
+    proj_x, proj_u = box_projectors(cfg)
+    traces = []
+    for b in range(Bt):
+        obj, get_AB = make_ref_isls(cfg, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, False, proj_u, None, cfg["rho_u"], max_iter=3, L=L, J=J,
+                     relax=cfg["relax"], tol=0.0, trace=tr)
+        traces.append(tr)
+    pack_trace("o2", traces, n, m, N, J, out)
+
+    def run_di(c, b):
+        obj, get_AB = make_ref_isls(c, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, False, proj_u, None, c["rho_u"], max_iter=3, L=L, J=J,
+                     relax=c["relax"], tol=0.0, trace=tr)
+        return tr
+    sens = trace_sensitivity(cfg, [0, 1], run_di)
+    print("di3d O2 sensitivity to a 1e-15 input perturbation:", sens)
+    out["o2_sens_keys"] = np.array(list(sens.keys()))
+    out["o2_sens"] = np.array(list(sens.values()))
+    # natural stopping (tol=1e-3) -- exercises both ADMM stop rules and the outer stop rules
+    traces = []
+    for b in range(Bt):
+        obj, get_AB = make_ref_isls(cfg, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, False, proj_u, None, cfg["rho_u"], max_iter=8, L=L, J=10,
+                     relax=cfg["relax"], tol=1e-3, trace=tr)
+        traces.append(tr)
+    pack_trace("o2stop", traces, n, m, N, 10, out)
+    # relaxation != 1 and a state box as well (rho_x scalar)
+    cfgx = dict(cfg)
+    cfgx["x_lo"] = np.full((N, n), -np.inf)
+    cfgx["x_hi"] = np.full((N, n), np.inf)
+    cfgx["x_lo"][:, 3:6], cfgx["x_hi"][:, 3:6] = -1.2, 1.2
+    proj_x2, _ = box_projectors(cfgx)
+    traces = []
+    for b in range(Bt):
+        obj, get_AB = make_ref_isls(cfgx, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, proj_x2, proj_u, 0.05, cfg["rho_u"], max_iter=2, L=L, J=4,
+                     relax=1.5, tol=0.0, trace=tr)
+        traces.append(tr)
+    pack_trace("o2x", traces, n, m, N, 4, out)
+    out["o2x_x_lo"], out["o2x_x_hi"] = cfgx["x_lo"], cfgx["x_hi"]
+
+    # --- cross-check O2 against the reference's own batch-form ilqr_admm (shimmed) -------------
+    obj, get_AB = make_ref_isls(cfg, 0)
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        logs_b = obj.ilqr_admm(get_AB, project_u=proj_u, max_iter=1, max_line_search_iter=L, max_admm_iter=J,
+                               rho_u=cfg["rho_u"], alpha=1.0, tol=0.0, log=True)
+    o2logs = out["o2_logs"][0, 0]
+    err_logs = np.max(np.abs(np.stack(logs_b) - o2logs))
+    err_x = np.max(np.abs(obj.x_nom - out["o2_xx"][0, 0, J - 1]))
+    err_u = np.max(np.abs(obj.u_nom[:-1] - out["o2_xu"][0, 0, J - 1][:-1]))
+    print(f"O2 vs reference batch-form ilqr_admm: logs {err_logs:.2e}, x {err_x:.2e}, u[:-1] {err_u:.2e}")
+    assert err_logs < 1e-9 and err_x < 1e-9 and err_u < 1e-8
+    out["xcheck_batchform"] = np.array([err_logs, err_x, err_u])
+    save("g3_di3d.npz", **out)
+
+
+def gen_arm():
+    out = {}
+    cfg = P.config3(batch=2, N=100, seed=0)
+    n, m, N = cfg["n"], cfg["m"], cfg["N"]
+    # --- pin: Task 2 of the robust notebook (recorded initial/converged costs) -----------------
+    cfg2 = dict(cfg)
+    target = np.array([0, 0, 0, 0, 0, 0, 1.5, 2.0, 0.0])
+    Qf = np.diag([0, 0, 0, 1e3, 1e3, 1e3, 1e3, 1e3, 0.0])
+    cfg2["zs"], cfg2["Qs"], cfg2["seq"] = P.via_point_cost(n, N, target, Qf)
+    cfg2["u0"] = np.zeros_like(cfg["u0"])
+    obj, get_AB = make_ref_isls(cfg2, 0)
+    assert obj.cost == 6775.068343357641, obj.cost          # robust notebook :351
+    for i in range(30):
+        obj.A, obj.B = get_AB(obj.x_nom, obj.u_nom)
+        ok, _, _ = obj.iterate_once_dp(max_line_search=20)
+        if np.abs(np.diff(obj.cost_log[-2:])) < 1e-5 or not ok:
+            break
+    print("arm task2 cost log", obj.cost_log)
+    assert abs(obj.cost - 0.1180803005667605) < 1e-9
+    out["task2_cost_log"] = np.array(obj.cost_log, dtype=float)
+    # --- Task 1: kernel-level + iLQR + O2 with the notebook constraint set ----------------------
+    L, J = cfg["max_line_search"], cfg["max_admm_iter"]
+    Kq, kq, AA, BB, logs = [], [], [], [], []
+    for b in range(2):
+        obj, get_AB = make_ref_isls(cfg, b)
+        A, B = get_AB(obj.x_nom, obj.u_nom)
+        obj.A, obj.B = A, B
+        AA.append(A.copy()), BB.append(B.copy())
+        K, k = obj.backward_pass_DP()
+        Kq.append(K), kq.append(k)
+        for i in range(30):
+            obj.A, obj.B = get_AB(obj.x_nom, obj.u_nom)
+            ok, _, _ = obj.iterate_once_dp(max_line_search=20)
+            if np.abs(np.diff(obj.cost_log[-2:])) < 1e-5 or not ok:
+                break
+        logs.append(np.pad(np.array(obj.cost_log, dtype=float), (0, 32 - len(obj.cost_log)), constant_values=np.nan))
+    out.update(lin_A=np.stack(AA), lin_B=np.stack(BB), bp_quad_K=np.stack(Kq), bp_quad_k=np.stack(kq),
+               ilqr_cost_log=np.stack(logs))
+    proj_x, proj_u = box_projectors(cfg)
+    traces = []
+    for b in range(2):
+        obj, get_AB = make_ref_isls(cfg, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, proj_x, proj_u, cfg["rho_x"], cfg["rho_u"], max_iter=3, L=L, J=J,
+                     relax=1.0, tol=0.0, trace=tr)
+        traces.append(tr)
+    pack_trace("o2", traces, n, m, N, J, out)
+
+    def run_arm(c, b):
+        obj, get_AB = make_ref_isls(c, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, proj_x, proj_u, c["rho_x"], c["rho_u"], max_iter=3, L=L, J=J,
+                     relax=1.0, tol=0.0, trace=tr)
+        return tr
+    sens = trace_sensitivity(cfg, [0, 1], run_arm)
+    print("arm O2 sensitivity to a 1e-15 input perturbation:", sens)
+    out["o2_sens_keys"] = np.array(list(sens.keys()))
+    out["o2_sens"] = np.array(list(sens.values()))
+    # the notebook call itself (threshold=1e-4, natural stop) on trajectory 0: final cost only
+    obj, get_AB = make_ref_isls(cfg, 0)
+    tr = []
+    n_outer = o2_ilqr_admm(obj, get_AB, proj_x, proj_u, cfg["rho_x"], cfg["rho_u"], max_iter=20, L=L, J=J,
+                           relax=1.0, tol=1e-4, trace=tr)
+    out["o2_notebook_cost_log"] = np.array(obj.cost_log, dtype=float)
+    out["o2_notebook_n_outer"] = np.array(n_outer)
+    print("arm O2 notebook-call cost log:", obj.cost_log)
+    save("g4_arm3r.npz", **out)
+
+
+def gen_car():
+    out = {}
+    cfg = P.config4(batch=2, N=200, seed=0)
+    n, m, N = cfg["n"], cfg["m"], cfg["N"]
+    L, J = 20, cfg["max_admm_iter"]
+    AA, BB, Kq, kq = [], [], [], []
+    for b in range(2):
+        obj, get_AB = make_ref_isls(cfg, b)
+        A, B = get_AB(obj.x_nom, obj.u_nom)
+        obj.A, obj.B = A, B
+        AA.append(A.copy()), BB.append(B.copy())
+        K, k = obj.backward_pass_DP()
+        Kq.append(K), kq.append(k)
+    out.update(lin_A=np.stack(AA), lin_B=np.stack(BB), bp_quad_K=np.stack(Kq), bp_quad_k=np.stack(kq))
+    proj_x, proj_u = box_projectors(cfg)
+    traces = []
+    for b in range(2):
+        obj, get_AB = make_ref_isls(cfg, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, proj_x, proj_u, cfg["rho_x"], cfg["rho_u"], max_iter=3, L=L, J=J,
+                     relax=1.0, tol=0.0, trace=tr)
+        traces.append(tr)
+    pack_trace("o2", traces, n, m, N, J, out)
+
+    def run_car(c, b):
+        obj, get_AB = make_ref_isls(c, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, proj_x, proj_u, c["rho_x"], c["rho_u"], max_iter=3, L=L, J=J,
+                     relax=1.0, tol=0.0, trace=tr)
+        return tr
+    sens = trace_sensitivity(cfg, [0, 1], run_car)
+    print("car O2 sensitivity to a 1e-15 input perturbation:", sens)
+    out["o2_sens_keys"] = np.array(list(sens.keys()))
+    out["o2_sens"] = np.array(list(sens.values()))
+    # pin: the notebook's own initial cost (state constraints.ipynb:214), x0=[0,-2,pi/2,0], u0 = 0
+    c = dict(cfg)
+    c["x0"] = np.array([[0.0, -2.0, np.pi / 2, 0.0]])
+    c["u0"] = np.zeros((1, 500, 2))
+    c["N"], c["dt"] = 500, 15.0 / 500
+    c["zs"], c["Qs"], c["seq"] = P.via_point_cost(4, 500, [-5.0, -5.0, np.pi / 4, 0.0], 1e2 * np.eye(4))
+    obj, _ = make_ref_isls(c, 0)
+    print("car notebook initial cost", obj.cost)
+    out["notebook_initial_cost"] = np.array(obj.cost)
+    save("g5_car.npz", **out)
+
+
+def gen_projections():
+    rng = np.random.default_rng(3)
+    out = {}
+    x = rng.standard_normal((64, 5)) * 3
+    out["bound_in"], out["bound_out"] = x, refproj.project_bound(x, -1.5, 2.0)
+    zt = rng.standard_normal((200, 4)) * 2
+    zt[:10, -1] = -np.abs(zt[:10, -1]) * 5            # deep inside the polar cone
+    zt[10:20, :-1] *= 0.01                            # well inside the cone
+    out["soc_in"], out["soc_out"] = zt, refproj.project_soc_unit(zt.copy())
+    sq = rng.standard_normal((100, 2)) * 2
+    out["square_in"], out["square_out"] = sq, refproj.project_square_batch(sq.copy(), 1.0, 2.5)
+    qd = rng.standard_normal((100, 3)) * 2
+    out["quad_in"], out["quad_out"] = qd, refproj.project_quadratic_batch(qd.copy(), 0.5, 3.0)
+    a = rng.standard_normal((50, 3))
+    xl = rng.standard_normal((50, 3)) * 3
+    out["lin_in"], out["lin_a"] = xl, a
+    out["lin_out"] = refproj.project_linear_batch(xl.copy(), a, -0.5, 1.0)
+    # set intersection of two unit-SOC images (the chance-constraint rows)
+    from scipy.stats import norm
+    psi = norm.ppf(0.95)
+    Au = np.diag(np.sqrt([0.0, 0.01]))
+    mu = np.array([1.0, 0.0])
+    A_ = [np.concatenate([Au, (-mu / psi)[None]], 0), np.concatenate([Au, (mu / psi)[None]], 0)]
+    b_ = [np.append(np.zeros(2), 5.0 / psi), np.append(np.zeros(2), 5.0 / psi)]
+    y = rng.standard_normal((40, 2)) * np.array([6.0, 30.0])
+    out["setcvx_in"] = y
+    out["setcvx_A0"], out["setcvx_A1"], out["setcvx_b0"], out["setcvx_b1"] = A_[0], A_[1], b_[0], b_[1]
+    out["setcvx_out"] = refproj.project_set_convex(y.copy(), A_, b_, projections=[refproj.project_soc_unit] * 2,
+                                                   rho=1e1, max_iter=100, threshold=1e-3)
+    save("g6_projections.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj"]
+    for w in which:
+        {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections}[w]()

@@ -1,0 +1,318 @@
+"""Pin the CPU oracle (oracle/isls_oracle*.c) against golden vectors produced by RUNNING THE REFERENCE
+(tests/golden/make_golden.py).  fp64 tolerance: 1e-10 on max-abs error relative to max(1, |ref|_max)
+(BASELINE.json north_star: "within 1e-10 fp64")."""
+import numpy as np
+import pytest
+
+import isls_problems as P
+from helpers import ALPHAS, OracleDriver, problem_arrays, rel_err, rho_to_weights
+from isls import _capi as capi
+
+TOL = 1e-10
+
+
+def z(*s):
+    return np.zeros(s, dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------------------------------
+# G1: SLS path on the 1-D double integrator (unmodified reference)
+# ---------------------------------------------------------------------------------------------------
+def _di1d_setup(oracle, N, rho_u, rho_x=None):
+    c = P.config1(N)
+    n, m, B = 2, 1, 1
+    Qtab, ztab, seq = c["Qs"].copy(), c["zs"].copy(), c["seq"].copy()
+    Rr = rho_to_weights(rho_u, N, m)
+    Qr = rho_to_weights(rho_x, N, n)
+    Cxx, Cuu, c0x, c0u = z(B, N, n, n), z(B, N, m, m), z(B, N, n), z(B, N, m)
+    oracle.expand_quadratic(Qtab, ztab, seq, c["u_std"], c0x, c0u, Cxx=Cxx, Cuu=Cuu, Qr=Qr, Rr=Rr)
+    K, Quu, fac, Qux = z(B, N, m, n), z(B, N, m, m), z(B, N, m, m), z(B, N, m, n)
+    st = np.zeros(B, dtype=np.int32)
+    oracle.riccati_gain(c["A"], c["B"], Cxx, Cuu, K, Quu, fac, Qux, solve_mode=capi.SOLVE_INV, status=st)
+    assert st[0] == 0
+    return c, dict(Qtab=Qtab, ztab=ztab, seq=seq, Rr=Rr, Qr=Qr, c0x=c0x, c0u=c0u, K=K, Quu=Quu, fac=fac, Qux=Qux)
+
+
+@pytest.mark.parametrize("tag,N", [("n100", 100), ("n50", 50)])
+def test_sls_solve_dp_and_ff(oracle, golden, tag, N):
+    g = golden("g1_di1d_lqt.npz")
+    # unregularised solve_dp()
+    c, s = _di1d_setup(oracle, N, None)
+    k = z(1, N, 1)
+    oracle.riccati_ff(c["A"], c["B"], s["c0x"], s["c0u"], s["K"], s["Quu"], s["fac"], s["Qux"], k,
+                      solve_mode=capi.SOLVE_INV)
+    assert rel_err(s["K"][0], g[f"{tag}_dp_K"]) < TOL
+    assert rel_err(k[0], g[f"{tag}_dp_k"]) < TOL
+    # regularised solve_dp(Rr, ur) with logs
+    c, s = _di1d_setup(oracle, N, c["rho_u"])
+    for name, key in (("K", "reg_K"), ("Quu", "reg_Quu"), ("fac", "reg_Quu_inv"), ("Qux", "reg_Qux")):
+        assert rel_err(s[name][0], g[f"{tag}_{key}"]) < TOL, name
+    for urkey, kkey in (("reg_ur", "reg_k"), ("ff_ur", "ff_k")):
+        zu = g[f"{tag}_{urkey}"].reshape(1, N, 1).copy()
+        oracle.riccati_ff(c["A"], c["B"], s["c0x"], s["c0u"], s["K"], s["Quu"], s["fac"], s["Qux"], k,
+                          Rr=s["Rr"], zu=zu, lu=z(1, N, 1), solve_mode=capi.SOLVE_INV)
+        assert rel_err(k[0], g[f"{tag}_{kkey}"]) < TOL, kkey
+    # state regulariser too
+    c, s = _di1d_setup(oracle, N, c["rho_u"], rho_x=0.5)
+    zx = g[f"{tag}_regx_xr"].reshape(1, N, 2).copy()
+    zu = g[f"{tag}_reg_ur"].reshape(1, N, 1).copy()
+    oracle.riccati_ff(c["A"], c["B"], s["c0x"], s["c0u"], s["K"], s["Quu"], s["fac"], s["Qux"], k,
+                      Qr=s["Qr"], Rr=s["Rr"], zx=zx, lx=z(1, N, 2), zu=zu, lu=z(1, N, 1), solve_mode=capi.SOLVE_INV)
+    assert rel_err(s["K"][0], g[f"{tag}_regx_K"]) < TOL
+    assert rel_err(k[0], g[f"{tag}_regx_k"]) < TOL
+
+
+def _admm_lqt_dp(oracle, N, max_iter, tol):
+    """SLS.ADMM_LQT_DP (isls/sls.py:298-317) out of oracle kernels."""
+    c, s = _di1d_setup(oracle, N, P.config1(N)["rho_u"])
+    B, n, m = 1, 2, 1
+    par = np.concatenate([c["A"].ravel(), c["B"].ravel()])
+    k, xx, xu = z(B, N, m), z(B, N, n), z(B, N, m)
+    zu, lu = z(B, N, m), z(B, N, m)
+    res, prev = z(B, 2), np.full((B, 2), 1e6)
+    act = np.ones(B, dtype=np.int32)
+    u_lo, u_hi = np.full((N, m), c["u_lo"]), np.full((N, m), c["u_hi"])
+    x0 = c["x0"][None].copy()
+    logs = []
+    for it in range(max_iter):
+        oracle.riccati_ff(c["A"], c["B"], s["c0x"], s["c0u"], s["K"], s["Quu"], s["fac"], s["Qux"], k,
+                          Rr=s["Rr"], zu=zu, lu=lu, solve_mode=capi.SOLVE_INV)
+        oracle.rollout_ls(capi.MODEL_LTI, par, s["K"], k, z(B, N, n), z(B, N, m), np.ones(1), s["Qtab"], s["ztab"],
+                          s["seq"], c["u_std"], xx, xu, x0=x0, flags=capi.RO_ABSOLUTE)
+        oracle.admm_update(xx, xu, res, zu=zu, lu=lu, u_lo=u_lo, u_hi=u_hi, relax=1.0, tol_abs=tol, tol_rel=tol,
+                           res_prev=prev, active=act)
+        logs.append(res[0].copy())
+        if not act[0]:
+            break
+    return xx[0], xu[0], k[0], np.stack(logs)
+
+
+@pytest.mark.parametrize("tag,N", [("n100", 100), ("n50", 50)])
+def test_admm_lqt_dp(oracle, golden, tag, N):
+    g = golden("g1_di1d_lqt.npz")
+    x, u, k, logs = _admm_lqt_dp(oracle, N, 8, 0.0)
+    assert rel_err(logs, g[f"{tag}_admm8_logs"]) < TOL
+    assert rel_err(x.ravel(), g[f"{tag}_admm8_x"]) < TOL
+    assert rel_err(u.ravel(), g[f"{tag}_admm8_u"]) < TOL
+    assert rel_err(k, g[f"{tag}_admm8_k"]) < TOL
+    # natural stop (tol 1e-4, config 1 of BASELINE.json): same iteration count, same solution
+    x, u, k, logs = _admm_lqt_dp(oracle, N, 500, 1e-4)
+    gl = g[f"{tag}_admm_dp_logs"]
+    assert logs.shape == gl.shape
+    assert rel_err(logs, gl) < TOL
+    assert rel_err(x.ravel(), g[f"{tag}_admm_dp_x"]) < TOL
+    assert rel_err(u.ravel(), g[f"{tag}_admm_dp_u"]) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# G3: 3-D double integrator (headline system) -- kernel level
+# ---------------------------------------------------------------------------------------------------
+def test_di3d_backward_and_rollout(oracle, golden):
+    g = golden("g3_di3d.npz")
+    cfg = P.config2(batch=int(g["cfg_batch"]), N=100, seed=int(g["cfg_seed"]))
+    pa = problem_arrays(cfg, [0, 1])
+    B, N, n, m = 2, 100, 6, 3
+    d = OracleDriver(oracle, pa, project_u=False)
+    d.linearize_expand()
+    d.gain(), d.ff()
+    assert rel_err(d.K, g["bp_quad_K"]) < TOL
+    assert rel_err(d.k, g["bp_quad_k"]) < TOL
+    # candidate costs and candidate trajectories of rollout_DP
+    L = 20
+    cost_all = z(B, L)
+    d.rollout(L, cost_all=cost_all)
+    assert rel_err(cost_all, g["ro_costs"]) < TOL
+    assert (d.best == np.argmin(g["ro_costs"], axis=1)).all()
+    for j, l in enumerate((0, 7, 19)):
+        oracle.rollout_ls(pa["model"], pa["model_par"], d.K, d.k, d.xhat, d.uhat, ALPHAS[l:l + 1].copy(),
+                          pa["Qtab"], pa["ztab"], pa["seq"], pa["u_std"], d.xx, d.xu)
+        assert rel_err(d.xx, g["ro_x_sel"][:, j]) < TOL
+        assert rel_err(d.xu, g["ro_u_sel"][:, j]) < TOL
+    # iterate_once_dp: NaN rule + acceptance test
+    d.rollout(L, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST)
+    io = g["iter_once"]
+    assert (io[:, 0] == 1).all() and (d.status == 0).all()
+    assert rel_err(d.cost_new, io[:, 1]) < TOL
+    assert rel_err(d.xx.reshape(B, -1), io[:, 2:2 + N * n]) < TOL
+    assert rel_err(d.xu.reshape(B, -1), io[:, 2 + N * n:]) < TOL
+    # regularised general (Cts) branch
+    d2 = OracleDriver(oracle, pa, rho_x=0.3, rho_u=1e-2, project_x=True, project_u=True)
+    d2.zx[:], d2.zu[:] = g["bp_reg_rx"], g["bp_reg_ru"]
+    d2.linearize_expand()
+    d2.gain(), d2.ff()
+    assert rel_err(d2.K, g["bp_reg_K"]) < TOL
+    assert rel_err(d2.k, g["bp_reg_k"]) < TOL
+
+
+def _ilqr(oracle, pa, L, max_iter, tol_fun=1e-5):
+    """iterate_once_dp loop with the stop rules of iSLS.solve (isls/isls.py:107-132)."""
+    d = OracleDriver(oracle, pa, project_u=False)
+    logs = [[c[0]] for c in d.cost_log]
+    active = np.ones(d.B, dtype=np.int32)
+    for i in range(max_iter):
+        if not active.any():
+            break
+        d.admm_active[:] = active
+        d.status[:] = 0
+        d.linearize_expand()
+        d.gain(), d.ff()
+        d.rollout(L, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST)
+        for b in range(d.B):
+            if not active[b]:
+                continue
+            ok = not (d.status[b] & capi.ST_LS_REJECT)
+            if ok:
+                d.xhat[b], d.uhat[b], d.cost[b] = d.xx[b], d.xu[b], d.cost_new[b]
+                logs[b].append(float(d.cost[b]))
+            if (len(logs[b]) >= 2 and abs(logs[b][-1] - logs[b][-2]) < tol_fun) or not ok:
+                active[b] = 0
+    return logs
+
+
+def test_di3d_ilqr_cost_log(oracle, golden):
+    g = golden("g3_di3d.npz")
+    cfg = P.config2(batch=int(g["cfg_batch"]), N=100, seed=int(g["cfg_seed"]))
+    logs = _ilqr(oracle, problem_arrays(cfg, [0, 1]), 20, 10)
+    for b in range(2):
+        ref = g["ilqr_cost_log"][b]
+        ref = ref[~np.isnan(ref)]
+        assert len(logs[b]) == len(ref)
+        assert rel_err(logs[b], ref) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# O2 traces: full outer loop
+# ---------------------------------------------------------------------------------------------------
+def trace_tols(g, prefix, floor=TOL):
+    """Per-quantity tolerance max(floor, 10 x sensitivity): the golden file records how far the
+    REFERENCE's own trace moves under a 1e-15 relative input perturbation (conditioning probe in
+    tests/golden/make_golden.py: the arm problem, weights 1e6 vs 1e-4, amplifies it to ~1e-8).
+    Errors are max|a-b| over the compared block, scaled like the probe by max(1, |golden array|_max)."""
+    tol = {}
+    if f"{prefix}_sens" in g.files:
+        tol = {str(k): max(floor, 10.0 * float(v)) for k, v in zip(g[f"{prefix}_sens_keys"], g[f"{prefix}_sens"])}
+    return tol
+
+
+def check_trace(trace, g, prefix, B, floor=TOL):
+    tols = trace_tols(g, prefix, floor)
+    alias = dict(regx="xx", regu="xu", zx="xx", zu="xu", lx="xx", lu="xu")
+
+    def chk(key, mine, o, b, i=None):
+        ref_all = g[f"{prefix}_{key}"]
+        scale = max(1.0, float(np.nanmax(np.abs(ref_all))))
+        ref = ref_all[b, o] if i is None else ref_all[b, o, i]
+        err = float(np.max(np.abs(np.asarray(mine, dtype=np.float64) - ref))) / scale
+        t = tols.get(alias.get(key, key), floor)
+        assert err < t, (prefix, key, "traj", b, "outer", o, "inner", i, err, t)
+
+    n_outer_ref = g[f"{prefix}_n_outer"]
+    for b in range(B):
+        n_o = sum(1 for it in trace if it["active"][b])
+        assert n_o == n_outer_ref[b], (prefix, b, n_o, n_outer_ref[b])
+    for o, it in enumerate(trace):
+        for b in range(B):
+            if not it["active"][b]:
+                continue
+            ji = int(g[f"{prefix}_n_inner"][b, o])
+            assert it["n_inner"][b] == ji, (prefix, "n_inner", b, o, it["n_inner"][b], ji)
+            chk("K", it["K"][b], o, b)
+            for i in range(ji):
+                for key in ("k", "xx", "xu", "logs", "regx", "regu"):
+                    if it[key][i] is not None:
+                        chk(key, it[key][i][b], o, b, i)
+            chk("cost", it["cost"][b], o, b)
+            for key in ("zx", "zu", "lx", "lu"):
+                if it[key] is not None:
+                    chk(key, it[key][b], o, b)
+
+
+def test_di3d_o2_fixed(oracle, golden):
+    g = golden("g3_di3d.npz")
+    cfg = P.config2(batch=int(g["cfg_batch"]), N=100, seed=int(g["cfg_seed"]))
+    d = OracleDriver(oracle, problem_arrays(cfg, [0, 1]), rho_u=cfg["rho_u"], relax=cfg["relax"])
+    tr = d.run(3, 20, 5, 0.0)
+    check_trace(tr, g, "o2", 2)
+
+
+def test_di3d_o2_natural_stop(oracle, golden):
+    g = golden("g3_di3d.npz")
+    cfg = P.config2(batch=int(g["cfg_batch"]), N=100, seed=int(g["cfg_seed"]))
+    d = OracleDriver(oracle, problem_arrays(cfg, [0, 1]), rho_u=cfg["rho_u"], relax=cfg["relax"])
+    tr = d.run(8, 20, 10, 1e-3)
+    check_trace(tr, g, "o2stop", 2)
+
+
+def test_di3d_o2_state_box_relaxed(oracle, golden):
+    g = golden("g3_di3d.npz")
+    cfg = P.config2(batch=int(g["cfg_batch"]), N=100, seed=int(g["cfg_seed"]))
+    pa = problem_arrays(cfg, [0, 1])
+    pa["x_lo"], pa["x_hi"] = g["o2x_x_lo"], g["o2x_x_hi"]
+    d = OracleDriver(oracle, pa, rho_x=0.05, rho_u=cfg["rho_u"], project_x=True, relax=1.5)
+    tr = d.run(2, 20, 4, 0.0)
+    check_trace(tr, g, "o2x", 2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# G4: planar 3R arm, G5: car
+# ---------------------------------------------------------------------------------------------------
+def test_arm_linearize_backward_ilqr(oracle, golden):
+    g = golden("g4_arm3r.npz")
+    cfg = P.config3(batch=2, N=100, seed=0)
+    pa = problem_arrays(cfg, [0, 1])
+    d = OracleDriver(oracle, pa, project_u=False)
+    d.linearize_expand()
+    assert rel_err(d.A, g["lin_A"]) < TOL and rel_err(d.Bm, g["lin_B"]) < TOL
+    d.gain(), d.ff()
+    assert rel_err(d.K, g["bp_quad_K"]) < TOL
+    assert rel_err(d.k, g["bp_quad_k"]) < TOL
+    logs = _ilqr(oracle, pa, 20, 30)
+    for b in range(2):
+        ref = g["ilqr_cost_log"][b]
+        ref = ref[~np.isnan(ref)]
+        assert len(logs[b]) == len(ref)
+        assert rel_err(logs[b], ref) < 1e-9      # costs start at 3.3e6 with 1e6 weights
+
+
+def test_arm_task2_notebook_pin(oracle, golden):
+    """Recorded notebook numbers: initial cost 6775.068343357641, converged 0.11808030056... (6 its)."""
+    g = golden("g4_arm3r.npz")
+    cfg = P.config3(batch=1, N=100, seed=0)
+    cfg["zs"], cfg["Qs"], cfg["seq"] = P.via_point_cost(9, 100, [0, 0, 0, 0, 0, 0, 1.5, 2.0, 0.0],
+                                                         np.diag([0, 0, 0, 1e3, 1e3, 1e3, 1e3, 1e3, 0.0]))
+    cfg["u0"] = np.zeros_like(cfg["u0"])
+    logs = _ilqr(oracle, problem_arrays(cfg, [0]), 20, 30)
+    ref = g["task2_cost_log"]
+    assert abs(logs[0][0] - 6775.068343357641) < 1e-9
+    assert len(logs[0]) == len(ref)
+    assert rel_err(logs[0], ref) < TOL
+    assert abs(logs[0][-1] - 0.1180803005667605) < 1e-9
+
+
+def test_arm_o2(oracle, golden):
+    g = golden("g4_arm3r.npz")
+    cfg = P.config3(batch=2, N=100, seed=0)
+    d = OracleDriver(oracle, problem_arrays(cfg, [0, 1]), rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+    tr = d.run(3, cfg["max_line_search"], cfg["max_admm_iter"], 0.0)
+    check_trace(tr, g, "o2", 2)
+    # the notebook call (threshold 1e-4, natural stop) on the notebook's own trajectory
+    d = OracleDriver(oracle, problem_arrays(cfg, [0]), rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+    d.run(20, cfg["max_line_search"], cfg["max_admm_iter"], 1e-4)
+    ref = g["o2_notebook_cost_log"]
+    assert len(d.cost_log[0]) == len(ref)
+    assert rel_err(d.cost_log[0][:4], ref[:4]) < 1e-8 and np.allclose(d.cost_log[0], ref, rtol=1e-7, atol=0)
+
+
+def test_car_o2(oracle, golden):
+    g = golden("g5_car.npz")
+    cfg = P.config4(batch=2, N=200, seed=0)
+    pa = problem_arrays(cfg, [0, 1])
+    d = OracleDriver(oracle, pa, project_u=False)
+    d.linearize_expand()
+    assert rel_err(d.A, g["lin_A"]) < TOL and rel_err(d.Bm, g["lin_B"]) < TOL
+    d.gain(), d.ff()
+    assert rel_err(d.K, g["bp_quad_K"]) < TOL
+    assert rel_err(d.k, g["bp_quad_k"]) < TOL
+    d = OracleDriver(oracle, pa, rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+    tr = d.run(3, 20, cfg["max_admm_iter"], 0.0)
+    check_trace(tr, g, "o2", 2)
