@@ -1,0 +1,170 @@
+// capi.hip -- extern "C" surface of libisls_hip.so (declared in include/isls_hip.h) and the
+// stream-ordered driver of one outer DP-form iLQR-ADMM iteration.
+#include <vector>
+
+#include "isls_common.hpp"
+
+namespace isls {
+
+// ---- optional per-kernel-family timing with HIP events on the launch stream -----------------------
+// (bench.py reads these: average launch duration of the dominant kernel for the roofline line)
+struct Timing {
+    bool on = false;
+    static constexpr int kKinds = 4;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[kKinds];
+    size_t used[kKinds] = {0, 0, 0, 0};
+};
+static Timing g_timing;
+
+struct ScopedTimer {
+    int kind;
+    hipStream_t s;
+    hipEvent_t stop = nullptr;
+    ScopedTimer(int kind_, hipStream_t s_) : kind(kind_), s(s_)
+    {
+        if (!g_timing.on) return;
+        auto &pool = g_timing.ev[kind];
+        size_t &u = g_timing.used[kind];
+        if (u == pool.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            pool.emplace_back(a, b);
+        }
+        hipEventRecord(pool[u].first, s);
+        stop = pool[u].second;
+        ++u;
+    }
+    ~ScopedTimer()
+    {
+        if (stop) hipEventRecord(stop, s);
+    }
+};
+
+template <typename T>
+static int outer_iteration(const isls_outer_args &a, hipStream_t s)
+{
+    const isls_admm_args &ad = a.admm;
+    int rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, s);
+    if (rc != ISLS_OK) return rc;
+    if (!a.skip_gain) {
+        ScopedTimer tm(0, s);
+        if ((rc = launch_gain<T>(a.gain, s)) != ISLS_OK) return rc;
+    }
+    for (int j = 0; j < a.J; ++j) {
+        {
+            ScopedTimer tm(1, s);
+            if ((rc = launch_ff<T>(a.ff, s)) != ISLS_OK) return rc;
+        }
+        {
+            ScopedTimer tm(2, s);
+            if ((rc = launch_rollout<T>(a.ro, s)) != ISLS_OK) return rc;
+        }
+        {
+            ScopedTimer tm(3, s);
+            if ((rc = launch_admm<T>(a.admm, s)) != ISLS_OK) return rc;
+        }
+        if (a.log) {
+            if (hipMemcpyAsync((T *)a.log + (size_t)j * ad.B * 2, ad.res, sizeof(T) * (size_t)ad.B * 2,
+                               hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return ISLS_ERR_LAUNCH;
+        }
+    }
+    return ISLS_OK;
+}
+
+}  // namespace isls
+
+using namespace isls;
+
+#define ISLS_API extern "C" __attribute__((visibility("default")))
+
+#define DEFINE_ENTRY(name, args_t, launcher, kind)                                        \
+    ISLS_API int isls_##name##_f64(const args_t *a, void *stream)                          \
+    {                                                                                      \
+        if (!a) return ISLS_ERR_ARG;                                                       \
+        ScopedTimer tm(kind, (hipStream_t)stream);                                         \
+        return launcher<double>(*a, (hipStream_t)stream);                                  \
+    }                                                                                      \
+    ISLS_API int isls_##name##_f32(const args_t *a, void *stream)                          \
+    {                                                                                      \
+        if (!a) return ISLS_ERR_ARG;                                                       \
+        ScopedTimer tm(kind, (hipStream_t)stream);                                         \
+        return launcher<float>(*a, (hipStream_t)stream);                                   \
+    }
+
+DEFINE_ENTRY(riccati_gain, isls_gain_args, launch_gain, 0)
+DEFINE_ENTRY(riccati_ff, isls_ff_args, launch_ff, 1)
+DEFINE_ENTRY(rollout_ls, isls_rollout_args, launch_rollout, 2)
+DEFINE_ENTRY(admm_update, isls_admm_args, launch_admm, 3)
+
+ISLS_API int isls_expand_quadratic_f64(const isls_expand_args *a, void *stream)
+{
+    return a ? launch_expand<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_expand_quadratic_f32(const isls_expand_args *a, void *stream)
+{
+    return a ? launch_expand<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_linearize_f64(const isls_linearize_args *a, void *stream)
+{
+    return a ? launch_linearize<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_linearize_f32(const isls_linearize_args *a, void *stream)
+{
+    return a ? launch_linearize<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_reduce_convergence_f64(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                         const int32_t *status, void *out5, void *stream)
+{
+    return launch_reduce<double>(B, cost, res, active, status, out5, (hipStream_t)stream);
+}
+ISLS_API int isls_reduce_convergence_f32(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                         const int32_t *status, void *out5, void *stream)
+{
+    return launch_reduce<float>(B, cost, res, active, status, out5, (hipStream_t)stream);
+}
+ISLS_API int isls_ilqr_admm_outer_f64(const isls_outer_args *a, void *stream)
+{
+    return a ? outer_iteration<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_ilqr_admm_outer_f32(const isls_outer_args *a, void *stream)
+{
+    return a ? outer_iteration<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+
+ISLS_API int isls_version(void) { return ISLS_VERSION; }
+
+ISLS_API const char *isls_error_string(int code)
+{
+    switch (code) {
+        case ISLS_OK: return "ok";
+        case ISLS_ERR_ARG: return "bad argument (null pointer or dimension)";
+        case ISLS_ERR_UNSUPPORTED: return "unsupported (n,m) pair, model, projection or L";
+        case ISLS_ERR_LAUNCH: return "HIP launch failed";
+        default: return "unknown";
+    }
+}
+
+ISLS_API int isls_timing_enable(int on)
+{
+    g_timing.on = on != 0;
+    for (int k = 0; k < Timing::kKinds; ++k) g_timing.used[k] = 0;
+    return 0;
+}
+
+// Sum of the event-bracketed durations of kernel family `kind` since isls_timing_enable(1); *count =
+// number of launches.  Synchronises on the recorded events (call it outside the timed region).
+ISLS_API double isls_timing_read_ms(int kind, int *count)
+{
+    if (kind < 0 || kind >= Timing::kKinds) return -1.0;
+    double total = 0.0;
+    const size_t n = g_timing.used[kind];
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        hipEventSynchronize(g_timing.ev[kind][i].second);
+        if (hipEventElapsedTime(&ms, g_timing.ev[kind][i].first, g_timing.ev[kind][i].second) == hipSuccess) total += ms;
+    }
+    if (count) *count = (int)n;
+    return total;
+}

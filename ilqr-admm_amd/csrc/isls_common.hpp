@@ -1,0 +1,157 @@
+// isls_common.hpp -- shared device helpers for the gfx950 kernels of libisls_hip.so.
+//
+// Execution model used by every time-recursive kernel here (Riccati gain / feed-forward, rollout):
+//   * a workgroup is ONE 64-lane wavefront (blockDim.x == 64);
+//   * the wavefront is cut into TPW "slots" of G lanes; one slot owns one trajectory for the whole
+//     horizon (the recursion is sequential in t, parallel over trajectories and over matrix rows /
+//     line-search candidates inside the slot);
+//   * per-step operands are fetched from HBM by the slot's lanes with cooperative contiguous loads
+//     one step AHEAD of their use (register staging), written to the slot's LDS record, and then
+//     consumed from LDS as broadcast (all lanes of a slot read the same word) or column reads.
+// Nothing in here assumes a dispatch order or an XCD placement.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/isls_hip.h"
+
+namespace isls {
+
+constexpr int kWave = 64;
+
+template <typename T>
+struct View {
+    const T *p;
+    int64_t sb, st;
+    __host__ __device__ View() : p(nullptr), sb(0), st(0) {}
+    __host__ __device__ explicit View(const isls_view &v) : p(static_cast<const T *>(v.p)), sb(v.sb), st(v.st) {}
+    __device__ __forceinline__ const T *at(int b, int t) const { return p + (int64_t)b * sb + (int64_t)t * st; }
+};
+
+// Cooperative load of CNT contiguous elements by the G lanes of a slot: lane i gets src[i + G*j].
+template <int CNT, int G, typename T>
+__device__ __forceinline__ void coop_load(const T *src, T (&r)[(CNT + G - 1) / G], int i, bool ok)
+{
+#pragma unroll
+    for (int j = 0; j < (CNT + G - 1) / G; ++j) {
+        const int e = i + G * j;
+        r[j] = (ok && e < CNT) ? src[e] : T(0);
+    }
+}
+template <int CNT, int G, typename T>
+__device__ __forceinline__ void coop_put(T *dst, const T (&r)[(CNT + G - 1) / G], int i, bool ok)
+{
+#pragma unroll
+    for (int j = 0; j < (CNT + G - 1) / G; ++j) {
+        const int e = i + G * j;
+        if (ok && e < CNT) dst[e] = r[j];
+    }
+}
+
+// Upper Cholesky Quu = U'U in registers (unblocked, column order of LAPACK dpotf2 'U').
+// U keeps the strict upper part; rd[j] = 1 / U_jj.  Returns false if a pivot is not positive.
+template <int M, typename T>
+__device__ __forceinline__ bool chol_upper(const T (&A)[M][M], T (&U)[M][M], T (&rd)[M])
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        T ajj = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) ajj -= U[k][j] * U[k][j];
+        ok = ok && (ajj > T(0));
+        const T d = sqrt(ajj);
+        U[j][j] = d;
+        rd[j] = T(1) / d;
+#pragma unroll
+        for (int c = j + 1; c < M; ++c) {
+            T s = A[j][c];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= U[k][j] * U[k][c];
+            U[j][c] = s * rd[j];
+        }
+    }
+    return ok;
+}
+// x = (U'U)^{-1} b with the reciprocal diagonal rd.
+template <int M, typename T>
+__device__ __forceinline__ void chol_solve(const T (&U)[M][M], const T (&rd)[M], const T (&b)[M], T (&x)[M])
+{
+    T y[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        T s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= U[k][i] * y[k];
+        y[i] = s * rd[i];
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+        T s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < M; ++k) s -= U[i][k] * x[k];
+        x[i] = s * rd[i];
+    }
+}
+
+// 64-lane butterfly sum (every lane ends with the total).
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T w = __shfl_xor(v, o, 64);
+        v = (w > v) ? w : v;
+    }
+    return v;
+}
+
+// numpy's float `%`: fmod followed by a sign fix (result takes the sign of the divisor).
+__device__ __forceinline__ double py_mod(double a, double b)
+{
+    double r = fmod(a, b);
+    if (r != 0.0 && ((b < 0.0) != (r < 0.0))) r += b;
+    return r;
+}
+__device__ __forceinline__ float py_mod(float a, float b)
+{
+    float r = fmodf(a, b);
+    if (r != 0.0f && ((b < 0.0f) != (r < 0.0f))) r += b;
+    return r;
+}
+
+// Launch wrappers implemented one per .hip file; each returns ISLS_OK / ISLS_ERR_*.
+template <typename T> int launch_gain(const isls_gain_args &a, hipStream_t s);
+template <typename T> int launch_ff(const isls_ff_args &a, hipStream_t s);
+template <typename T> int launch_rollout(const isls_rollout_args &a, hipStream_t s);
+template <typename T> int launch_admm(const isls_admm_args &a, hipStream_t s);
+template <typename T> int launch_expand(const isls_expand_args &a, hipStream_t s);
+template <typename T> int launch_linearize(const isls_linearize_args &a, hipStream_t s);
+template <typename T> int launch_reduce(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                        const int32_t *status, void *out5, hipStream_t s);
+template <typename T> int launch_outer_begin(int32_t B, int32_t N, int32_t n, int32_t m, int32_t *admm_active,
+                                             const int32_t *outer_active, void *lx, void *lu, void *res_prev,
+                                             hipStream_t s);
+
+inline int check_launch()
+{
+    return hipGetLastError() == hipSuccess ? ISLS_OK : ISLS_ERR_LAUNCH;
+}
+
+// supported (n, m) pairs: the reference notebooks' systems
+#define ISLS_DISPATCH_DIMS(n, m, CALL)              \
+    if ((n) == 6 && (m) == 3) { CALL(6, 3); }       \
+    else if ((n) == 2 && (m) == 1) { CALL(2, 1); }  \
+    else if ((n) == 4 && (m) == 2) { CALL(4, 2); }  \
+    else if ((n) == 9 && (m) == 3) { CALL(9, 3); }  \
+    else return ISLS_ERR_UNSUPPORTED;
+
+}  // namespace isls

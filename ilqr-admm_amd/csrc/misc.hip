@@ -1,0 +1,270 @@
+// misc.hip -- the streaming kernels either side of the recursions (gfx950):
+//   expand_quadratic : via-point quadratic cost expansion about the nominal + nominal cost
+//                      (isls/isls.py:263-271, isls/sls.py:132-137, isls/sls_base.py:25-44)
+//   linearize        : A_t, B_t of the built-in models along the nominal (notebooks' get_AB callbacks)
+//   reduce_convergence / outer_begin : bookkeeping of the outer loop (isls/isls.py:414-421, admm.py:25-26)
+// All are HBM-bound: one wavefront per trajectory, flat coalesced sweeps over the trajectory's arrays.
+#include "isls_common.hpp"
+
+namespace isls {
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct ExpP {
+    int B, N, n, m;
+    const T *Qtab, *ztab;
+    int64_t Qtab_sb, ztab_sb;
+    const int32_t *seq;
+    T u_std;
+    View<T> Qr, Rr;
+    const T *xhat, *uhat;
+    T *Cxx, *Cuu, *c0x, *c0u, *cost;
+    const int32_t *active;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void expand_kernel(ExpP<T> p)
+{
+    const int b = blockIdx.x;
+    if (p.active && p.active[b] == 0) return;
+    const int N = p.N, n = p.n, m = p.m, lane = threadIdx.x;
+    const T *Qtab = p.Qtab + (int64_t)b * p.Qtab_sb, *ztab = p.ztab + (int64_t)b * p.ztab_sb;
+    const int64_t bN = (int64_t)b * N;
+    T cx_sum = T(0), cu_sum = T(0);
+    // c0x[t,i] = 2 * sum_j Q_t[i,j] (xhat[t,j] - z_t[j]);   cost_x = sum d_i (Q d)_i
+    for (int e = lane; e < N * n; e += kWave) {
+        const int t = e / n, i = e - t * n;
+        const T *Q = Qtab + (int64_t)p.seq[t] * n * n + i * n, *z = ztab + (int64_t)p.seq[t] * n;
+        const T *xh = p.xhat ? p.xhat + (bN + t) * n : nullptr;
+        T sacc = T(0);
+        for (int j = 0; j < n; ++j) sacc += Q[j] * ((xh ? xh[j] : T(0)) - z[j]);
+        p.c0x[bN * n + e] = T(2) * sacc;
+        cx_sum += ((xh ? xh[i] : T(0)) - z[i]) * sacc;
+    }
+    for (int e = lane; e < N * m; e += kWave) {
+        const T uu = p.uhat ? p.uhat[bN * m + e] : T(0);
+        p.c0u[bN * m + e] = T(2) * (p.u_std * uu);
+        cu_sum += uu * (p.u_std * uu);
+    }
+    if (p.Cxx) {
+        for (int e = lane; e < N * n * n; e += kWave) {
+            const int t = e / (n * n), r = e - t * n * n;
+            T v = T(2) * Qtab[(int64_t)p.seq[t] * n * n + r];
+            if (p.Qr.p) v += T(2) * p.Qr.at(b, t)[r];
+            p.Cxx[bN * n * n + e] = v;
+        }
+    }
+    if (p.Cuu) {
+        for (int e = lane; e < N * m * m; e += kWave) {
+            const int t = e / (m * m), r = e - t * m * m;
+            T v = ((r / m) == (r % m)) ? T(2) * p.u_std : T(0);
+            if (p.Rr.p) v += T(2) * p.Rr.at(b, t)[r];
+            p.Cuu[bN * m * m + e] = v;
+        }
+    }
+    if (p.cost) {
+        cx_sum = wave_sum(cx_sum);
+        cu_sum = wave_sum(cu_sum);
+        if (lane == 0) p.cost[b] = cx_sum + cu_sum;
+    }
+}
+
+template <typename T>
+int launch_expand(const isls_expand_args &a, hipStream_t s)
+{
+    if (a.B < 0 || a.N < 1 || a.n < 1 || a.m < 1 || !a.Qtab || !a.ztab || !a.seq || !a.c0x || !a.c0u) return ISLS_ERR_ARG;
+    if (a.B == 0) return ISLS_OK;
+    ExpP<T> p;
+    p.B = a.B; p.N = a.N; p.n = a.n; p.m = a.m;
+    p.Qtab = (const T *)a.Qtab; p.ztab = (const T *)a.ztab; p.Qtab_sb = a.Qtab_sb; p.ztab_sb = a.ztab_sb;
+    p.seq = a.seq; p.u_std = (T)a.u_std;
+    p.Qr = View<T>(a.Qr); p.Rr = View<T>(a.Rr);
+    p.xhat = (const T *)a.xhat; p.uhat = (const T *)a.uhat;
+    p.Cxx = (T *)a.Cxx; p.Cuu = (T *)a.Cuu; p.c0x = (T *)a.c0x; p.c0u = (T *)a.c0u; p.cost = (T *)a.cost;
+    p.active = a.active;
+    hipLaunchKernelGGL((expand_kernel<T>), dim3(a.B), dim3(64), 0, s, p);
+    return check_launch();
+}
+template int launch_expand<double>(const isls_expand_args &, hipStream_t);
+template int launch_expand<float>(const isls_expand_args &, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct LinP {
+    int B, N, n, m, model;
+    const T *par;
+    int64_t par_sb;
+    const T *xhat, *uhat;
+    T *A, *Bm;
+    const int32_t *active;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void linearize_kernel(LinP<T> p)
+{
+    extern __shared__ __align__(16) unsigned char lin_smem[];
+    T *tab = reinterpret_cast<T *>(lin_smem);                 // [N][8] per-step trig terms
+    const int b = blockIdx.x;
+    if (p.active && p.active[b] == 0) return;
+    const int N = p.N, n = p.n, m = p.m, lane = threadIdx.x;
+    const T *par = p.par + (int64_t)b * p.par_sb;
+    const int64_t bN = (int64_t)b * N;
+    T *A = p.A + bN * n * n, *Bm = p.Bm + bN * n * m;
+    if (p.model == ISLS_MODEL_LTI) {
+        for (int e = lane; e < N * n * n; e += kWave) A[e] = par[e % (n * n)];
+        for (int e = lane; e < N * n * m; e += kWave) Bm[e] = par[n * n + e % (n * m)];
+        return;
+    }
+    const T dt = par[0];
+    if (p.model == ISLS_MODEL_ARM3R) {
+        // phase 1: J(q + qd dt + u dt^2/2) per step: tab[t] = {J00,J01,J02,J10,J11,J12}
+        for (int t = lane; t < N; t += kWave) {
+            const T *x = p.xhat + (bN + t) * 9, *u = p.uhat + (bN + t) * 3;
+            T c = T(0), sn[3], cs[3];
+            for (int j = 0; j < 3; ++j) {
+                c += x[j] + x[3 + j] * dt + T(0.5) * u[j] * (dt * dt);
+                sn[j] = sin(c); cs[j] = cos(c);
+            }
+            for (int j = 0; j < 3; ++j) {
+                T j0 = T(0), j1 = T(0);
+                for (int i = j; i < 3; ++i) { j0 += sn[i]; j1 += cs[i]; }
+                tab[t * 8 + j] = -j0;
+                tab[t * 8 + 3 + j] = j1;
+            }
+        }
+        __syncthreads();
+        // phase 2: flat coalesced fill (3DoF notebooks cell 10)
+        for (int e = lane; e < N * 81; e += kWave) {
+            const int t = e / 81, r = (e - t * 81) / 9, c = e % 9;
+            T v = T(0);
+            if (r < 6) v = (r == c) ? T(1) : ((r < 3 && c == r + 3) ? dt : T(0));
+            else if (r < 8 && c < 3) v = tab[t * 8 + (r - 6) * 3 + c];
+            else if (r < 8 && c < 6) v = tab[t * 8 + (r - 6) * 3 + (c - 3)] * dt;
+            A[e] = v;
+        }
+        for (int e = lane; e < N * 27; e += kWave) {
+            const int t = e / 27, r = (e - t * 27) / 3, c = e % 3;
+            T v = T(0);
+            if (r < 3) v = (r == c) ? T(0.5) * (dt * dt) : T(0);
+            else if (r < 6) v = (r - 3 == c) ? dt : T(0);
+            else if (r < 8) v = (T(0.5) * tab[t * 8 + (r - 6) * 3 + c]) * (dt * dt);
+            Bm[e] = v;
+        }
+        return;
+    }
+    // car-simple (Car notebooks cell 6): tab[t] = {sin th, cos th, v, u0}
+    for (int t = lane; t < N; t += kWave) {
+        const T *x = p.xhat + (bN + t) * 4, *u = p.uhat + (bN + t) * 2;
+        tab[t * 8 + 0] = sin(x[2]); tab[t * 8 + 1] = cos(x[2]); tab[t * 8 + 2] = x[3]; tab[t * 8 + 3] = u[0];
+    }
+    __syncthreads();
+    for (int e = lane; e < N * 16; e += kWave) {
+        const int t = e / 16, r = (e % 16) / 4, c = e % 4;
+        const T sn = tab[t * 8], cs = tab[t * 8 + 1], v_ = tab[t * 8 + 2], u0 = tab[t * 8 + 3];
+        T v = (r == c) ? T(1) : T(0);
+        if (r == 0 && c == 2) v = -dt * v_ * sn;
+        else if (r == 1 && c == 2) v = dt * v_ * cs;
+        else if (r == 0 && c == 3) v = dt * cs;
+        else if (r == 1 && c == 3) v = dt * sn;
+        else if (r == 2 && c == 3) v = dt * u0;
+        A[e] = v;
+    }
+    for (int e = lane; e < N * 8; e += kWave) {
+        const int t = e / 8, r = (e % 8) / 2, c = e % 2;
+        T v = T(0);
+        if (r == 2 && c == 0) v = dt * tab[t * 8 + 2];
+        else if (r == 3 && c == 1) v = dt;
+        Bm[e] = v;
+    }
+}
+
+template <typename T>
+int launch_linearize(const isls_linearize_args &a, hipStream_t s)
+{
+    if (a.B < 0 || a.N < 1 || !a.model_par || !a.A || !a.Bm) return ISLS_ERR_ARG;
+    if (a.model != ISLS_MODEL_LTI && (!a.xhat || !a.uhat)) return ISLS_ERR_ARG;
+    if (a.model == ISLS_MODEL_ARM3R && !(a.n == 9 && a.m == 3)) return ISLS_ERR_UNSUPPORTED;
+    if (a.model == ISLS_MODEL_CAR && !(a.n == 4 && a.m == 2)) return ISLS_ERR_UNSUPPORTED;
+    if (a.model < ISLS_MODEL_LTI || a.model > ISLS_MODEL_CAR) return ISLS_ERR_UNSUPPORTED;
+    if ((size_t)a.N * 8 * sizeof(T) > 60000) return ISLS_ERR_UNSUPPORTED;
+    if (a.B == 0) return ISLS_OK;
+    LinP<T> p;
+    p.B = a.B; p.N = a.N; p.n = a.n; p.m = a.m; p.model = a.model;
+    p.par = (const T *)a.model_par; p.par_sb = a.model_par_sb;
+    p.xhat = (const T *)a.xhat; p.uhat = (const T *)a.uhat; p.A = (T *)a.A; p.Bm = (T *)a.Bm; p.active = a.active;
+    hipLaunchKernelGGL((linearize_kernel<T>), dim3(a.B), dim3(64), (size_t)a.N * 8 * sizeof(T), s, p);
+    return check_launch();
+}
+template int launch_linearize<double>(const isls_linearize_args &, hipStream_t);
+template int launch_linearize<float>(const isls_linearize_args &, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// out5 = { sum cost, max prim, max dual, #active, #status!=0 } over the local shard (single workgroup)
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_kernel(int B, const T *cost, const T *res, const int32_t *active,
+                                                     const int32_t *status, T *out5)
+{
+    __shared__ T sm[5][4];
+    T cs = T(0), pm = T(0), dm = T(0), na = T(0), nf = T(0);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        if (cost) cs += cost[b];
+        if (res) { pm = res[2 * b] > pm ? res[2 * b] : pm; dm = res[2 * b + 1] > dm ? res[2 * b + 1] : dm; }
+        na += (active == nullptr || active[b] != 0) ? T(1) : T(0);
+        if (status) nf += status[b] != 0 ? T(1) : T(0);
+    }
+    cs = wave_sum(cs); na = wave_sum(na); nf = wave_sum(nf); pm = wave_max(pm); dm = wave_max(dm);
+    const int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) { sm[0][w] = cs; sm[1][w] = pm; sm[2][w] = dm; sm[3][w] = na; sm[4][w] = nf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T o0 = T(0), o1 = T(0), o2 = T(0), o3 = T(0), o4 = T(0);
+        for (int i = 0; i < 4; ++i) {
+            o0 += sm[0][i]; o3 += sm[3][i]; o4 += sm[4][i];
+            o1 = sm[1][i] > o1 ? sm[1][i] : o1;
+            o2 = sm[2][i] > o2 ? sm[2][i] : o2;
+        }
+        out5[0] = o0; out5[1] = o1; out5[2] = o2; out5[3] = o3; out5[4] = o4;
+    }
+}
+
+template <typename T>
+int launch_reduce(int32_t B, const void *cost, const void *res, const int32_t *active, const int32_t *status,
+                  void *out5, hipStream_t s)
+{
+    if (B < 0 || !out5) return ISLS_ERR_ARG;
+    hipLaunchKernelGGL((reduce_kernel<T>), dim3(1), dim3(256), 0, s, (int)B, (const T *)cost, (const T *)res, active,
+                       status, (T *)out5);
+    return check_launch();
+}
+template int launch_reduce<double>(int32_t, const void *, const void *, const int32_t *, const int32_t *, void *, hipStream_t);
+template int launch_reduce<float>(int32_t, const void *, const void *, const int32_t *, const int32_t *, void *, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// start of an outer iteration: admm_active <- outer_active, lambda <- 0 (isls.py:414-415,482),
+// previous residual norms <- 1e6 (admm.py:25-26), for the trajectories still iterating.
+template <typename T>
+__global__ __launch_bounds__(64) void outer_begin_kernel(int N, int n, int m, int32_t *admm_active,
+                                                         const int32_t *outer_active, T *lx, T *lu, T *res_prev)
+{
+    const int b = blockIdx.x;
+    const bool act = outer_active == nullptr || outer_active[b] != 0;
+    if (threadIdx.x == 0 && admm_active) admm_active[b] = act ? 1 : 0;
+    if (!act) return;
+    if (lx) for (int e = threadIdx.x; e < N * n; e += kWave) lx[(int64_t)b * N * n + e] = T(0);
+    if (lu) for (int e = threadIdx.x; e < N * m; e += kWave) lu[(int64_t)b * N * m + e] = T(0);
+    if (res_prev && threadIdx.x < 2) res_prev[(int64_t)b * 2 + threadIdx.x] = T(1e6);
+}
+
+template <typename T>
+int launch_outer_begin(int32_t B, int32_t N, int32_t n, int32_t m, int32_t *admm_active, const int32_t *outer_active,
+                       void *lx, void *lu, void *res_prev, hipStream_t s)
+{
+    if (B <= 0) return ISLS_OK;
+    hipLaunchKernelGGL((outer_begin_kernel<T>), dim3(B), dim3(64), 0, s, (int)N, (int)n, (int)m, admm_active, outer_active,
+                       (T *)lx, (T *)lu, (T *)res_prev);
+    return check_launch();
+}
+template int launch_outer_begin<double>(int32_t, int32_t, int32_t, int32_t, int32_t *, const int32_t *, void *, void *, void *, hipStream_t);
+template int launch_outer_begin<float>(int32_t, int32_t, int32_t, int32_t, int32_t *, const int32_t *, void *, void *, void *, hipStream_t);
+
+}  // namespace isls

@@ -1,0 +1,476 @@
+// riccati.hip -- backward Riccati pass on gfx950: gain pass and feed-forward pass.
+//
+// Reference semantics: iSLS.backward_pass_DP (isls/isls.py:229-308), SLS.solve_dp / solve_dp_ff
+// (isls/sls.py:85-202).  See include/isls_hip.h for the exact formulas and array formats.
+//
+// Mapping (both kernels): one 64-lane wavefront per workgroup, cut into TPW = 64/(n+m) slots of
+// G = n+m lanes; slot s owns trajectory blockIdx.x*TPW + s.  Lane i of a slot owns ROW i of the
+// stacked (n+m) x (n+m) matrix [Qxx Qxu; Qux Quu] = C + [A B]' V [A B]:
+//     S_i  = sum_k [A B][k,i] * V[k,:]          (row i of [A B]'V,   n FMAs x n)
+//     M_i  = sum_k S_i[k]   * [A B][k,:]        (row i of the stack, n FMAs x (n+m))
+// so lanes i<n end up with a row of Qxx, lanes i>=n with a row of [Qux Quu].  V, [A B] and the small
+// factors live in the slot's LDS record and are read back as broadcasts (all lanes of a slot read the
+// same word) or as the lane's own column.  A_t, B_t (and C_t rows) of step t-1 are fetched from HBM
+// while step t is being computed (register staging), so the sequential chain only waits on LDS.
+#include "isls_common.hpp"
+
+namespace isls {
+
+// ================================================================================================
+// Gain pass
+// ================================================================================================
+template <typename T>
+struct GainP {
+    int B, N, mode;
+    View<T> A, Bm, Cxx, Cuu, Cux;
+    T *K, *Quu, *fac, *Qux;
+    int32_t *status;
+    const int32_t *active;
+};
+
+template <typename T, int NX, int NU>
+__global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
+{
+    constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
+    constexpr int V_OFF = 0, AB_OFF = V_OFF + NX * NX, Q_OFF = AB_OFF + NX * W, K_OFF = Q_OFF + NU * W;
+    constexpr int SLOT = ((K_OFF + NU * NX) | 1);          // odd stride: slots start on different banks
+    constexpr int JA = (NX * NX + G - 1) / G, JB = (NX * NU + G - 1) / G, JQ = (NU * W + G - 1) / G;
+    __shared__ T lds[TPW * SLOT];
+
+    const int lane = threadIdx.x;
+    const int s = lane / G, i = lane - s * G;
+    const int b = blockIdx.x * TPW + s;
+    const bool inslot = s < TPW;
+    const bool valid = inslot && b < p.B && (p.active == nullptr || p.active[b] != 0);
+    const int N = p.N;
+    T *rec = lds + (inslot ? s : TPW - 1) * SLOT;
+    T *Vs = rec + V_OFF, *ABs = rec + AB_OFF, *Qs = rec + Q_OFF, *Ks = rec + K_OFF;
+    const bool xl = i < NX;                                   // lane owns a row of Qxx
+    const int a_row = xl ? 0 : i - NX;                        // row of [Qux Quu] for u-lanes
+    const int64_t bN = (int64_t)(valid ? b : 0) * N;
+
+    // ---- terminal step: K[N-1] = 0 (isls.py:245), V = Cxx[N-1] (isls.py:251/257) -----------------
+    {
+        T r[JA];
+        coop_load<NX * NX, G>(p.Cxx.at(valid ? b : 0, N - 1), r, i, valid);
+        coop_put<NX * NX, G>(Vs, r, i, valid);
+        if (valid) {
+            const int64_t o = bN + (N - 1);
+#pragma unroll
+            for (int j = 0; j < (NU * NX + G - 1) / G; ++j) {
+                const int e = i + G * j;
+                if (e < NU * NX) { p.K[o * NU * NX + e] = T(0); p.Qux[o * NU * NX + e] = T(0); }
+            }
+#pragma unroll
+            for (int j = 0; j < (NU * NU + G - 1) / G; ++j) {
+                const int e = i + G * j;
+                if (e < NU * NU) { p.Quu[o * NU * NU + e] = T(0); p.fac[o * NU * NU + e] = T(0); }
+            }
+        }
+    }
+
+    // ---- register staging of step t operands ------------------------------------------------------
+    T ra[JA], rb[JB], crow[W];
+    auto fetch = [&](int t) {
+        const int bb = valid ? b : 0;
+        coop_load<NX * NX, G>(p.A.at(bb, t), ra, i, valid);
+        coop_load<NX * NU, G>(p.Bm.at(bb, t), rb, i, valid);
+        // row i of the cost Hessian stack: [Cxx[i,:]] or [Cux[a,:] Cuu[a,:]]
+        if (xl) {
+            const T *c = p.Cxx.at(bb, t) + i * NX;
+#pragma unroll
+            for (int j = 0; j < W; ++j) crow[j] = (valid && j < NX) ? c[j < NX ? j : 0] : T(0);
+        } else {
+            const T *cu = p.Cuu.at(bb, t) + a_row * NU;
+            const T *cx = p.Cux.p ? p.Cux.at(bb, t) + a_row * NX : nullptr;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) crow[j] = (valid && cx) ? cx[j] : T(0);
+#pragma unroll
+            for (int j = 0; j < NU; ++j) crow[NX + j] = valid ? cu[j] : T(0);
+        }
+    };
+    if (N >= 2) fetch(N - 2);
+    bool pd_ok = true;
+
+    for (int t = N - 2; t >= 0; --t) {
+        // stage [A_t B_t] into the record: row k = [A[k,:] B[k,:]]
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int e = i + G * j;
+            if (valid && e < NX * NX) ABs[(e / NX) * W + (e % NX)] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int e = i + G * j;
+            if (valid && e < NX * NU) ABs[(e / NU) * W + NX + (e % NU)] = rb[j];
+        }
+        T c_now[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) c_now[j] = crow[j];
+        __syncthreads();                                       // (a) ABs, Vs visible to the slot
+        if (t > 0) fetch(t - 1);                               // HBM loads for the next step fly during compute
+
+        // (1) S = row i of [A B]'V
+        T S[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) S[j] = T(0);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const T col = ABs[k * W + i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) S[j] += col * Vs[k * NX + j];
+        }
+        // (2) M = C_row + S [A B]      (Qxx = Cxx + (A'V)A etc., isls.py:288-290)
+        T M[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) M[c] = T(0);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) M[c] += S[k] * ABs[k * W + c];
+        }
+#pragma unroll
+        for (int c = 0; c < W; ++c) M[c] = c_now[c] + M[c];
+        // (3) u-lanes publish their row of [Qux Quu]
+        if (!xl && valid) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) Qs[a_row * W + c] = M[c];
+        }
+        __syncthreads();                                       // (b)
+
+        // (4) factor Quu (redundantly in every lane), solve for column i of K
+        T Quu[NU][NU], U[NU][NU], rd[NU], rhs[NU], Kc[NU];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) { Quu[r][c] = Qs[r * W + NX + c]; U[r][c] = T(0); }
+            rhs[r] = Qs[r * W + (xl ? i : 0)];                 // column i of Qux
+        }
+        pd_ok = chol_upper<NU>(Quu, U, rd) && pd_ok;
+        T inv[NU][NU];
+        if (p.mode == ISLS_SOLVE_CHOL) {
+            T x[NU];
+            chol_solve<NU>(U, rd, rhs, x);                     // sol = -solve(Quu, Qux)  (isls.py:296)
+#pragma unroll
+            for (int r = 0; r < NU; ++r) Kc[r] = -x[r];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {                     // Quu_inv column by column (sls.py:149)
+                T e[NU], x[NU];
+#pragma unroll
+                for (int r = 0; r < NU; ++r) e[r] = (r == c) ? T(1) : T(0);
+                chol_solve<NU>(U, rd, e, x);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) inv[r][c] = x[r];
+            }
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {                     // Kt = -Quu_inv.dot(Qux)  (sls.py:150)
+                T sacc = T(0);
+#pragma unroll
+                for (int c = 0; c < NU; ++c) sacc += inv[r][c] * rhs[c];
+                Kc[r] = -sacc;
+            }
+        }
+        const int64_t o = bN + t;
+        if (xl && valid) {
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                Ks[r * NX + i] = Kc[r];
+                p.K[(o * NU + r) * NX + i] = Kc[r];
+            }
+        }
+        if (valid) {
+            // cooperative store of [Qux Quu] rows
+#pragma unroll
+            for (int j = 0; j < JQ; ++j) {
+                const int e = i + G * j;
+                if (e < NU * W) {
+                    const int r = e / W, c = e % W;
+                    const T v = Qs[e];
+                    if (c < NX) p.Qux[(o * NU + r) * NX + c] = v;
+                    else p.Quu[(o * NU + r) * NU + (c - NX)] = v;
+                }
+            }
+            // factor: row r written by lane r (values are identical in every lane)
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                if (i == r) {
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) {
+                        T v;
+                        if (p.mode == ISLS_SOLVE_CHOL) v = (c == r) ? rd[r] : (c > r ? U[r][c] : T(0));
+                        else v = inv[r][c];
+                        p.fac[(o * NU + r) * NU + c] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                       // (c) Ks visible
+
+        // (5) V row i = Qxx + (K'Quu)K + Qux'K + K'Qux   (isls.py:300 / sls.py:153), x-lanes only
+        if (xl) {
+            T Wr[NU];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                T sacc = T(0);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) sacc += Kc[r] * Quu[r][c];
+                Wr[c] = sacc;
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                T t1 = T(0), t2 = T(0), t3 = T(0);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+                    const T kj = Ks[r * NX + j];
+                    t1 += Wr[r] * kj;                          // (K'Quu) K
+                    t2 += rhs[r] * kj;                         // Qux' K
+                    t3 += Kc[r] * Qs[r * W + j];               // K' Qux
+                }
+                const T vn = (p.mode == ISLS_SOLVE_CHOL) ? ((M[j] + t1) + t2) + t3 : ((M[j] + t2) + t3) + t1;
+                if (valid) Vs[i * NX + j] = vn;
+            }
+        }
+    }
+    if (valid && i == 0 && !pd_ok && p.status) atomicOr(&p.status[b], ISLS_ST_NOT_PD);
+}
+
+template <typename T>
+int launch_gain(const isls_gain_args &a, hipStream_t s)
+{
+    if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.Cxx.p || !a.Cuu.p || !a.K || !a.Quu || !a.fac || !a.Qux)
+        return ISLS_ERR_ARG;
+    if (a.solve_mode != ISLS_SOLVE_CHOL && a.solve_mode != ISLS_SOLVE_INV) return ISLS_ERR_ARG;
+    if (a.B == 0) return ISLS_OK;
+    GainP<T> p;
+    p.B = a.B; p.N = a.N; p.mode = a.solve_mode;
+    p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.Cxx = View<T>(a.Cxx); p.Cuu = View<T>(a.Cuu); p.Cux = View<T>(a.Cux);
+    p.K = (T *)a.K; p.Quu = (T *)a.Quu; p.fac = (T *)a.fac; p.Qux = (T *)a.Qux;
+    p.status = a.status; p.active = a.active;
+#define CALL(NX_, NU_)                                                                        \
+    {                                                                                         \
+        constexpr int TPW = kWave / (NX_ + NU_);                                              \
+        const int grid = (a.B + TPW - 1) / TPW;                                               \
+        hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_>), dim3(grid), dim3(64), 0, s, p); \
+    }
+    ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
+#undef CALL
+    return check_launch();
+}
+template int launch_gain<double>(const isls_gain_args &, hipStream_t);
+template int launch_gain<float>(const isls_gain_args &, hipStream_t);
+
+// ================================================================================================
+// Feed-forward pass
+// ================================================================================================
+template <typename T>
+struct FfP {
+    int B, N, mode;
+    View<T> A, Bm, c0x, c0u, Qr, Rr;
+    const T *xhat, *uhat, *zx, *lx, *zu, *lu;
+    const T *K, *Quu, *fac, *Qux;
+    T *k;
+    const int32_t *active;
+};
+
+template <typename T, int NX, int NU>
+__global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
+{
+    constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
+    constexpr int AB_OFF = 0, K_OFF = AB_OFF + NX * W, QUX_OFF = K_OFF + NU * NX, QUU_OFF = QUX_OFF + NU * NX,
+                  FAC_OFF = QUU_OFF + NU * NU, D_OFF = FAC_OFF + NU * NU, V_OFF = D_OFF + W, QU_OFF = V_OFF + NX;
+    constexpr int SLOT = ((QU_OFF + NU) | 1);
+    constexpr int JA = (NX * NX + G - 1) / G, JB = (NX * NU + G - 1) / G, JK = (NU * NX + G - 1) / G,
+                  JU = (NU * NU + G - 1) / G;
+    __shared__ T lds[TPW * SLOT];
+
+    const int lane = threadIdx.x;
+    const int s = lane / G, i = lane - s * G;
+    const int b = blockIdx.x * TPW + s;
+    const bool inslot = s < TPW;
+    const bool valid = inslot && b < p.B && (p.active == nullptr || p.active[b] != 0);
+    const int N = p.N;
+    const int bb = valid ? b : 0;
+    T *rec = lds + (inslot ? s : TPW - 1) * SLOT;
+    T *ABs = rec + AB_OFF, *Ks = rec + K_OFF, *Quxs = rec + QUX_OFF, *Quus = rec + QUU_OFF, *Facs = rec + FAC_OFF,
+      *Ds = rec + D_OFF, *Vs = rec + V_OFF, *Qus = rec + QU_OFF;
+    const bool xl = i < NX;
+    const int iu = xl ? 0 : i - NX;
+    const int64_t bN = (int64_t)bb * N;
+    const bool hasx = p.Qr.p != nullptr, hasu = p.Rr.p != nullptr;
+    const bool hasreg = xl ? hasx : hasu;
+
+    // per-step staged operands
+    T ra[JA], rb[JB], rk[JK], rq[JK], ruu[JU], rf[JU];
+    T c0, dreg, rrow[NX];                                  // own gradient entry, own reg difference, own Qr/Rr row
+    auto fetch = [&](int t, bool factors) {
+        const int64_t o = bN + t;
+        if (factors) {
+            coop_load<NX * NX, G>(p.A.at(bb, t), ra, i, valid);
+            coop_load<NX * NU, G>(p.Bm.at(bb, t), rb, i, valid);
+            coop_load<NU * NX, G>(p.K + o * NU * NX, rk, i, valid);
+            coop_load<NU * NX, G>(p.Qux + o * NU * NX, rq, i, valid);
+            coop_load<NU * NU, G>(p.Quu + o * NU * NU, ruu, i, valid);
+            coop_load<NU * NU, G>(p.fac + o * NU * NU, rf, i, valid);
+        }
+        c0 = valid ? (xl ? p.c0x.at(bb, t)[i] : p.c0u.at(bb, t)[iu]) : T(0);
+        dreg = T(0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) rrow[j] = T(0);
+        if (valid && hasreg) {
+            if (xl) {
+                const T xh = p.xhat ? p.xhat[o * NX + i] : T(0);
+                dreg = xh - (p.zx[o * NX + i] - p.lx[o * NX + i]);
+                const T *q = p.Qr.at(bb, t) + i * NX;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) rrow[j] = q[j];
+            } else {
+                const T uh = p.uhat ? p.uhat[o * NU + iu] : T(0);
+                dreg = uh - (p.zu[o * NU + iu] - p.lu[o * NU + iu]);
+                const T *q = p.Rr.at(bb, t) + iu * NU;
+#pragma unroll
+                for (int j = 0; j < NU; ++j) rrow[j] = q[j];
+            }
+        }
+    };
+    // cx_i / cu_i = c0 + 2 * (row of Qr/Rr) . d       (isls/sls.py:132-137; O2 of SURVEY 8c)
+    auto reg_grad = [&](T c0v, const T (&row)[NX]) -> T {
+        T sacc = T(0);
+        if (xl) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) sacc += row[j] * Ds[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) sacc += row[j] * Ds[NX + j];
+        }
+        return hasreg ? c0v + T(2) * sacc : c0v;
+    };
+
+    // ---- terminal step: v = cx[N-1], k[N-1] = 0 ------------------------------------------------------
+    fetch(N - 1, false);
+    if (valid) Ds[i] = dreg;
+    __syncthreads();
+    {
+        const T cterm = reg_grad(c0, rrow);
+        if (valid && xl) Vs[i] = cterm;
+        if (valid && !xl) p.k[(bN + N - 1) * NU + iu] = T(0);
+    }
+    if (N >= 2) fetch(N - 2, true);
+    __syncthreads();
+
+    for (int t = N - 2; t >= 0; --t) {
+        // stage the prefetched operands of step t
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int e = i + G * j;
+            if (valid && e < NX * NX) ABs[(e / NX) * W + (e % NX)] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int e = i + G * j;
+            if (valid && e < NX * NU) ABs[(e / NU) * W + NX + (e % NU)] = rb[j];
+        }
+        coop_put<NU * NX, G>(Ks, rk, i, valid);
+        coop_put<NU * NX, G>(Quxs, rq, i, valid);
+        coop_put<NU * NU, G>(Quus, ruu, i, valid);
+        coop_put<NU * NU, G>(Facs, rf, i, valid);
+        if (valid) Ds[i] = dreg;
+        const T c0_now = c0;
+        T row_now[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) row_now[j] = rrow[j];
+        __syncthreads();                                       // (a) record + v of the previous step visible
+        if (t > 0) fetch(t - 1, true);
+
+        // q_i = c_i + ([A B]' v)_i        (isls.py:285-286)
+        const T ci = reg_grad(c0_now, row_now);
+        T sacc = T(0);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) sacc += ABs[k * W + i] * Vs[k];
+        const T qi = ci + sacc;
+        if (valid && !xl) Qus[iu] = qi;
+        __syncthreads();                                       // (b) qu visible
+
+        // k_t = -Quu^{-1} qu  (every lane), then v_i for x-lanes
+        T qu[NU], kt[NU];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) qu[r] = Qus[r];
+        if (p.mode == ISLS_SOLVE_CHOL) {
+            T U[NU][NU], rd[NU], x[NU];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+#pragma unroll
+                for (int c = 0; c < NU; ++c) U[r][c] = Facs[r * NU + c];
+                rd[r] = Facs[r * NU + r];
+            }
+            chol_solve<NU>(U, rd, qu, x);
+#pragma unroll
+            for (int r = 0; r < NU; ++r) kt[r] = -x[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                T acc = T(0);
+#pragma unroll
+                for (int c = 0; c < NU; ++c) acc += Facs[r * NU + c] * qu[c];
+                kt[r] = -acc;
+            }
+        }
+        T vnew = T(0);
+        if (xl) {
+            T t_kqu = T(0), t_kquuk = T(0), t_quxk = T(0);
+            T Kc[NU];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) { Kc[r] = Ks[r * NX + i]; t_kqu += Kc[r] * qu[r]; }
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                T w = T(0);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) w += Kc[r] * Quus[r * NU + c];
+                t_kquuk += w * kt[c];
+            }
+#pragma unroll
+            for (int r = 0; r < NU; ++r) t_quxk += Quxs[r * NX + i] * kt[r];
+            vnew = (p.mode == ISLS_SOLVE_CHOL) ? ((qi + t_kqu) + t_kquuk) + t_quxk      // isls.py:302
+                                               : ((qi + t_quxk) + t_kqu) + t_kquuk;     // sls.py:200
+        } else if (valid) {
+            T kv = kt[0];
+#pragma unroll
+            for (int r = 1; r < NU; ++r) kv = (iu == r) ? kt[r] : kv;
+            p.k[(bN + t) * NU + iu] = kv;
+        }
+        __syncthreads();                                       // (c) everyone has read v
+        if (valid && xl) Vs[i] = vnew;
+    }
+}
+
+template <typename T>
+int launch_ff(const isls_ff_args &a, hipStream_t s)
+{
+    if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.c0x.p || !a.c0u.p || !a.K || !a.Quu || !a.fac || !a.Qux || !a.k)
+        return ISLS_ERR_ARG;
+    if (a.Qr.p && (!a.zx || !a.lx)) return ISLS_ERR_ARG;
+    if (a.Rr.p && (!a.zu || !a.lu)) return ISLS_ERR_ARG;
+    if (a.solve_mode != ISLS_SOLVE_CHOL && a.solve_mode != ISLS_SOLVE_INV) return ISLS_ERR_ARG;
+    if (a.B == 0) return ISLS_OK;
+    FfP<T> p;
+    p.B = a.B; p.N = a.N; p.mode = a.solve_mode;
+    p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.c0x = View<T>(a.c0x); p.c0u = View<T>(a.c0u);
+    p.Qr = View<T>(a.Qr); p.Rr = View<T>(a.Rr);
+    p.xhat = (const T *)a.xhat; p.uhat = (const T *)a.uhat;
+    p.zx = (const T *)a.zx; p.lx = (const T *)a.lx; p.zu = (const T *)a.zu; p.lu = (const T *)a.lu;
+    p.K = (const T *)a.K; p.Quu = (const T *)a.Quu; p.fac = (const T *)a.fac; p.Qux = (const T *)a.Qux;
+    p.k = (T *)a.k; p.active = a.active;
+#define CALL(NX_, NU_)                                                                      \
+    {                                                                                       \
+        constexpr int TPW = kWave / (NX_ + NU_);                                            \
+        const int grid = (a.B + TPW - 1) / TPW;                                             \
+        hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_>), dim3(grid), dim3(64), 0, s, p); \
+    }
+    ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
+#undef CALL
+    return check_launch();
+}
+template int launch_ff<double>(const isls_ff_args &, hipStream_t);
+template int launch_ff<float>(const isls_ff_args &, hipStream_t);
+
+}  // namespace isls

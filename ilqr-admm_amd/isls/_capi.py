@@ -57,7 +57,7 @@ class RolloutArgs(C.Structure):
                 ("K", C.c_void_p), ("k", C.c_void_p), ("xhat", C.c_void_p), ("uhat", C.c_void_p),
                 ("x0", C.c_void_p), ("alphas", C.c_void_p),
                 ("Qtab", C.c_void_p), ("Qtab_sb", C.c_int64), ("ztab", C.c_void_p), ("ztab_sb", C.c_int64),
-                ("seq", C.c_void_p), ("u_std", C.c_double),
+                ("seq", C.c_void_p), ("q_nonzero", C.c_void_p), ("u_std", C.c_double),
                 ("wq", View), ("wr", View),
                 ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
                 ("cost_cur", C.c_void_p), ("cost_all", C.c_void_p), ("best", C.c_void_p),
@@ -263,7 +263,7 @@ class Kernels:
     @staticmethod
     def rollout_args(model, model_par, K, k, xhat, uhat, alphas, Qtab, ztab, seq, u_std, x_out, u_out,
                      best=None, cost_new=None, cost_all=None, x0=None, wq=None, wr=None, zx=None, lx=None,
-                     zu=None, lu=None, cost_cur=None, flags=0, status=None, active=None):
+                     zu=None, lu=None, cost_cur=None, flags=0, status=None, active=None, q_nonzero=None):
         B, N, m, n = K.shape
         L = int(alphas.shape[0])
         nvia = int(Qtab.shape[-3])
@@ -282,6 +282,9 @@ class Kernels:
         if tuple(seq.shape) != (N,):
             raise ValueError("seq must be int32[N]")
         a.seq = _ptr(seq)
+        if q_nonzero is not None and tuple(q_nonzero.shape) != (N,):
+            raise ValueError("q_nonzero must be int32[N]")
+        a.q_nonzero = _ptr(q_nonzero)
         a.wq, a.wr = make_view(wq, B, N, (n,), "wq"), make_view(wr, B, N, (m,), "wr")
         if wq is not None and (zx is None or lx is None):
             raise ValueError("wq given without zx/lx")

@@ -153,6 +153,7 @@ typedef struct isls_rollout_args {
     const void *ztab;               /* [.,nvia,n] */
     int64_t ztab_sb;
     const int32_t *seq;             /* [N] */
+    const int32_t *q_nonzero;       /* [N] nullable hint: 0 where Q_t == 0 for every trajectory (term skipped) */
     double u_std;
     isls_view wq;                   /* [.,.,n] nullable */
     isls_view wr;                   /* [.,.,m] nullable */
@@ -249,8 +250,9 @@ int isls_reduce_convergence_f32(int32_t B, const void *cost, const void *res, co
  * One outer DP-form iLQR-ADMM iteration enqueued as a whole (SURVEY 3.3 with the dense solve
  * replaced by the Riccati pass): gain -> J x [ ff -> rollout/line-search -> ADMM update ].
  * The sub-structs are used as given; between inner iterations nothing is exchanged with the host.
- * `log` (nullable) receives res per inner iteration: log[j,B,2].  `admm_active` is set from
- * `outer_active` (nullable => all ones) before the first inner iteration.
+ * `log` (nullable) receives res per inner iteration: log[j,B,2].  Before the first inner iteration,
+ * for the trajectories with outer_active[b]!=0 (nullable => all): admm.active[b] <- 1, lambda <- 0
+ * (isls/isls.py:414-415,482), res_prev <- 1e6 (isls/admm.py:25-26); the others get admm.active[b] <- 0.
  * ------------------------------------------------------------------------------------------- */
 typedef struct isls_outer_args {
     isls_gain_args gain;

@@ -332,7 +332,7 @@ static void FN(rollout_one)(const isls_rollout_args *a, int b, REAL alpha, REAL 
             u[r] = (s + alpha * k[t * m + r]) + ((absolute || !uh) ? (REAL)0 : uh[t * m + r]);
         }
         if (xs) { for (int i = 0; i < n; ++i) xs[t * n + i] = x[i]; for (int i = 0; i < m; ++i) us[t * m + i] = u[i]; }
-        if (cost) {
+        if (cost && (!a->q_nonzero || a->q_nonzero[t])) {
             const REAL *Q = Qtab + (int64_t)a->seq[t] * n * n, *z = ztab + (int64_t)a->seq[t] * n;
             REAL d[MAXN];
             for (int i = 0; i < n; ++i) d[i] = x[i] - z[i];
@@ -594,9 +594,17 @@ int FN(oracle_reduce_convergence)(int32_t B, const void *cost, const void *res, 
 int FN(oracle_ilqr_admm_outer)(const isls_outer_args *a)
 {
     int rc;
-    const int B = a->gain.B;
-    if (a->admm.active)
-        for (int b = 0; b < B; ++b) a->admm.active[b] = a->outer_active ? a->outer_active[b] : 1;
+    const int B = a->gain.B, N = a->admm.N, n = a->admm.n, m = a->admm.m;
+    /* start of an outer iteration: admm_active <- outer_active, lambda <- 0 (isls.py:414-415,482),
+     * previous residual norms <- 1e6 (admm.py:25-26) for the trajectories still iterating */
+    for (int b = 0; b < B; ++b) {
+        const int act = a->outer_active ? (a->outer_active[b] != 0) : 1;
+        if (a->admm.active) a->admm.active[b] = act;
+        if (!act) continue;
+        if (a->admm.lx) for (int e = 0; e < N * n; ++e) ((REAL *)a->admm.lx)[(int64_t)b * N * n + e] = 0;
+        if (a->admm.lu) for (int e = 0; e < N * m; ++e) ((REAL *)a->admm.lu)[(int64_t)b * N * m + e] = 0;
+        if (a->admm.res_prev) { ((REAL *)a->admm.res_prev)[2 * b] = (REAL)1e6; ((REAL *)a->admm.res_prev)[2 * b + 1] = (REAL)1e6; }
+    }
     if (!a->skip_gain && (rc = FN(oracle_riccati_gain)(&a->gain)) != ISLS_OK) return rc;
     for (int j = 0; j < a->J; ++j) {
         if ((rc = FN(oracle_riccati_ff)(&a->ff)) != ISLS_OK) return rc;

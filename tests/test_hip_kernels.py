@@ -1,0 +1,125 @@
+"""GPU parity, kernel by kernel: every HIP kernel (through the C ABI) against the CPU oracle on identical
+seeded inputs, for the four systems of the BASELINE configs.  Tolerance: 1e-10 (fp64) on max-abs error
+relative to max(1,|ref|_max) per array; the ill-conditioned arm problem uses the conditioning-aware bound
+recorded in its golden file (see tests/test_oracle_golden.py::trace_tols)."""
+import numpy as np
+import pytest
+
+import isls_problems as P
+from helpers import OracleDriver, problem_arrays
+from isls import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dual(oracle):
+    from dual import DualKernels, hip_kernels
+    return lambda tol=1e-10: DualKernels(oracle, hip_kernels(), tol=tol)
+
+
+def _report(dk):
+    worst = sorted(dk.max_err.items(), key=lambda kv: -kv[1])[:6]
+    print("calls", dk.calls, "worst:", ", ".join(f"{k}={v:.1e}" for k, v in worst))
+
+
+@pytest.mark.parametrize("B", [1, 7, 23])
+def test_di3d_all_kernels(dual, B):
+    cfg = P.config2(batch=32, N=100, seed=1)
+    pa = problem_arrays(cfg, range(B))
+    dk = dual()
+    d = OracleDriver(dk, pa, rho_u=cfg["rho_u"], relax=cfg["relax"])
+    d.run(2, 20, 3, 0.0)
+    # state box + relaxation + natural stop (freezing of converged trajectories)
+    pa["x_lo"] = np.full((100, 6), -np.inf); pa["x_hi"] = np.full((100, 6), np.inf)
+    pa["x_lo"][:, 3:6], pa["x_hi"][:, 3:6] = -1.2, 1.2
+    d = OracleDriver(dk, pa, rho_x=0.05, rho_u=cfg["rho_u"], project_x=True, relax=1.5)
+    d.run(4, 20, 10, 1e-3)
+    _report(dk)
+
+
+def test_di3d_iterate_once_flags(dual):
+    cfg = P.config2(batch=16, N=100, seed=2)
+    pa = problem_arrays(cfg, range(9))
+    dk = dual()
+    d = OracleDriver(dk, pa, project_u=False)
+    for it in range(3):
+        d.linearize_expand()
+        d.gain(), d.ff()
+        d.rollout(20, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST, cost_all=np.zeros((9, 20)))
+        d.xhat[:], d.uhat[:], d.cost[:] = d.xx, d.xu, d.cost_new
+    # at the optimum no candidate improves: rejection path keeps the nominal
+    d.linearize_expand()
+    d.gain(), d.ff()
+    d.rollout(5, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST)
+    _report(dk)
+
+
+@pytest.mark.parametrize("L", [1, 5, 8, 20, 33, 50])
+def test_rollout_candidate_counts(dual, L):
+    cfg = P.config2(batch=16, N=100, seed=3)
+    pa = problem_arrays(cfg, range(11))
+    dk = dual()
+    d = OracleDriver(dk, pa, rho_u=cfg["rho_u"])
+    d.linearize_expand()
+    d.gain(), d.ff()
+    d.rollout(L, cost_all=np.zeros((11, L)))
+    _report(dk)
+
+
+def test_arm_all_kernels(dual, golden):
+    g = golden("g4_arm3r.npz")
+    sens = max(float(v) for v in g["o2_sens"])
+    cfg = P.config3(batch=16, N=100, seed=0)
+    pa = problem_arrays(cfg, range(7))
+    dk = dual(tol=max(1e-10, 10 * sens))
+    d = OracleDriver(dk, pa, rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+    d.run(3, cfg["max_line_search"], cfg["max_admm_iter"], 0.0)
+    _report(dk)
+
+
+def test_car_all_kernels(dual):
+    cfg = P.config4(batch=16, N=200, seed=0)
+    pa = problem_arrays(cfg, range(13))
+    dk = dual()
+    d = OracleDriver(dk, pa, rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+    d.run(3, 20, cfg["max_admm_iter"], 0.0)
+    _report(dk)
+
+
+def test_di1d_sls_inverse_mode(dual):
+    """SLS.solve_dp / solve_dp_ff / get_trajectory_dp path (explicit inverse, absolute coordinates)."""
+    from helpers import rho_to_weights
+    c = P.config1(50)
+    N, n, m, B = 50, 2, 1, 3
+    dk = dual()
+    z = lambda *s: np.zeros(s)   # noqa: E731
+    Rr = rho_to_weights(c["rho_u"], N, m)
+    Qr = rho_to_weights(0.5, N, n)
+    Cxx, Cuu, c0x, c0u = z(B, N, n, n), z(B, N, m, m), z(B, N, n), z(B, N, m)
+    dk.expand_quadratic(c["Qs"], c["zs"], c["seq"], c["u_std"], c0x, c0u, Cxx=Cxx, Cuu=Cuu, Qr=Qr, Rr=Rr)
+    K, Quu, fac, Qux, k = z(B, N, m, n), z(B, N, m, m), z(B, N, m, m), z(B, N, m, n), z(B, N, m)
+    st = np.zeros(B, dtype=np.int32)
+    dk.riccati_gain(c["A"], c["B"], Cxx, Cuu, K, Quu, fac, Qux, solve_mode=capi.SOLVE_INV, status=st)
+    rng = np.random.default_rng(0)
+    zx, zu = rng.standard_normal((B, N, n)), rng.standard_normal((B, N, m))
+    lx, lu = 0.1 * rng.standard_normal((B, N, n)), 0.1 * rng.standard_normal((B, N, m))
+    dk.riccati_ff(c["A"], c["B"], c0x, c0u, K, Quu, fac, Qux, k, Qr=Qr, Rr=Rr, zx=zx, lx=lx, zu=zu, lu=lu,
+                  solve_mode=capi.SOLVE_INV)
+    par = np.concatenate([c["A"].ravel(), c["B"].ravel()])
+    xx, xu = z(B, N, n), z(B, N, m)
+    x0 = rng.standard_normal((B, n)) * 0.1
+    dk.rollout_ls(capi.MODEL_LTI, par, K, k, z(B, N, n), z(B, N, m), np.ones(1), c["Qs"], c["zs"], c["seq"],
+                  c["u_std"], xx, xu, x0=x0, flags=capi.RO_ABSOLUTE, cost_new=z(B), best=np.zeros(B, dtype=np.int32))
+    _report(dk)
+
+
+def test_fp32_kernels(dual):
+    """fp32 build of every kernel against the fp32 oracle (north star: 1e-4 fp32)."""
+    cfg = P.config2(batch=16, N=100, seed=4)
+    pa = problem_arrays(cfg, range(10), dtype=np.float32)
+    dk = dual(tol=1e-4)
+    dk.int_exact = False            # near-ties of the arg-min may flip in fp32
+    d = OracleDriver(dk, pa, rho_u=cfg["rho_u"], relax=cfg["relax"], dtype=np.float32)
+    d.run(2, 20, 3, 0.0)
+    _report(dk)
