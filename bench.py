@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- iLQR-ADMM outer iterations per second on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (config 2 of BASELINE.json): 3-D double integrator iLQR-ADMM, fp64, per GPU
+B=4096 trajectories x N=100 steps, n=6, m=3, J=5 ADMM iterations per outer iteration, L=20 line-search
+candidates, box constraint on u, early exit disabled (fixed work).  A_t, B_t are passed in the general
+time-varying per-trajectory layout [B,N,n,n] (--lti uses the stride-0 shared layout instead).
+One "step" = one outer iteration over the rank's batch:
+    linearise + quadratic expansion -> Riccati gain pass -> J x [feed-forward pass -> L-candidate
+    rollout + cost + arg-min + winner -> ADMM projection/dual/residual update] -> nominal update ->
+    convergence reduction (+ one 40-byte RCCL all-reduce when N>1).
+Inputs are resident in HBM before the timed region.  Multi-GPU = weak scaling: every rank owns its own
+4096 trajectories; value = n_gpus * K / (max-over-ranks time)  [batch-4096 iterations per second].
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "ilqr-admm_amd"), ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+KIND_NAMES = ["riccati_gain_kernel", "riccati_ff_kernel", "rollout_kernel", "admm_update_kernel"]
+
+
+def algorithmic_bytes(n, m, N, w, has_x, has_u, lti):
+    """Compulsory HBM bytes per trajectory per launch of each kernel family (each distinct array once)."""
+    ab = 0 if lti else n * n + n * m
+    reg = (3 * n if has_x else 0) + (3 * m if has_u else 0)            # xhat/uhat, z, lambda of the regularised blocks
+    gain = ab + n * n + m * m + (2 * m * n + 2 * m * m)               # A,B,Cxx,Cuu in; K,Qux,Quu,fac out
+    ff = ab + 2 * m * n + 2 * m * m + (n + m) + reg + m               # A,B,K,Qux,Quu,fac,c0,reg in; k out
+    ro = m * n + m + (n + m) + ((2 * n if has_x else 0) + (2 * m if has_u else 0)) + (n + m)   # K,k,nominal,z,l in; x,u out
+    admm = (5 * n if has_x else 0) + (5 * m if has_u else 0)          # x,z,l in; z,l out
+    return [w * N * v for v in (gain, ff, ro, admm)]
+
+
+def iteration_bytes(n, m, N, w):
+    """SURVEY 8(d) official figure: bytes_traj = w*N*[2n^2 + 2nm + m^2 + m + 7(n+m)] (fully fused ideal)."""
+    return w * N * (2 * n * n + 2 * n * m + m * m + m + 7 * (n + m))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--J", type=int, default=5)
+    ap.add_argument("--L", type=int, default=20)
+    ap.add_argument("--lti", action="store_true", help="share A,B over batch and time (stride-0 views)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories in the CPU-baseline sample (0: auto)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import isls_problems as P
+    from isls import _capi as capi
+    from isls.engine import Engine, library
+
+    B, N, J, L = args.batch, args.horizon, args.J, args.L
+    cfg = P.config2(batch=B, N=N, seed=rank)
+    n, m = cfg["n"], cfg["m"]
+    eng = Engine(B, N, n, m, dtype=torch.float64, device=dev)
+    par = np.concatenate([cfg["A"].ravel(), cfg["B"].ravel()])
+    eng.set_model(capi.MODEL_LTI, par)
+    eng.set_quadratic_cost(cfg["zs"], cfg["Qs"], cfg["seq"], cfg["u_std"])
+    # initial nominal: u = 0 from x0 (the double integrator keeps position, zero velocity)
+    x_nom = np.repeat(cfg["x0"][:, None, :], N, axis=1)
+    eng.set_nominal(x_nom, cfg["u0"])
+    eng.set_admm(rho_u=cfg["rho_u"], u_box=(cfg["u_lo"], cfg["u_hi"]), relax=cfg["relax"])
+    if args.lti:
+        eng.A = torch.as_tensor(cfg["A"], device=dev).reshape(1, 1, n, n)
+        eng.Bm = torch.as_tensor(cfg["B"], device=dev).reshape(1, 1, n, m)
+    eng.build_outer(L, J, tol_abs=0.0, tol_rel=0.0)          # tolerances 0: no early exit, fixed work
+    red = torch.zeros(world, 5, dtype=torch.float64, device=dev)
+
+    def step():
+        if not args.lti:
+            eng.linearize()                                   # A_t,B_t of every trajectory rewritten in HBM
+        eng.expand()                                          # Cxx,Cuu,c0x,c0u about the nominal
+        eng.run_outer()                                       # gain + J x (ff, rollout, update), one C call
+        eng.accept_x_step()                                   # nominal <- x-step, cost log (no stop rule)
+        eng.reduce()
+        if dist is not None:
+            red.zero_()
+            red[rank].copy_(eng.out5)
+            dist.all_reduce(red)                              # the one collective: 5 doubles per rank
+        else:
+            red[0].copy_(eng.out5)
+
+    lib = library()
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lib.isls_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.isls_timing_enable(0)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- per-kernel-family durations from the HIP events recorded on the launch stream ------------
+    fam = []
+    for kind in range(4):
+        cnt = ctypes.c_int(0)
+        ms = lib.isls_timing_read_ms(kind, ctypes.byref(cnt))
+        fam.append((ms, cnt.value))
+    red_host = red.cpu().numpy()
+
+    if rank == 0:
+        it_per_s = world * args.steps / dt
+        w = 8
+        abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti)
+        dom = int(np.argmax([ms for ms, _ in fam]))
+        avg_ms = fam[dom][0] / max(1, fam[dom][1])
+        achieved = abytes[dom] * B / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        it_bytes = iteration_bytes(n, m, N, w) * B
+        out = {
+            "metric": "iLQR-ADMM iterations/sec, batch=4096 N=100 x_dim=6",
+            "value": it_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config2: 3-D double integrator iLQR-ADMM (DP form), box constraint on u",
+                       "batch_per_gpu": B, "horizon": N, "x_dim": n, "u_dim": m, "admm_iters_J": J,
+                       "line_search_L": L, "layout": "LTI stride-0 A,B" if args.lti else "time-varying A,B per trajectory",
+                       "early_exit": False, "trajectory_iterations_per_s": it_per_s * B,
+                       "admm_iterations_per_s": it_per_s * J},
+            "roofline": {"bound": "hbm", "kernel": KIND_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": abytes[dom] * B,
+                         "iteration_algorithmic_bytes": it_bytes,
+                         "iteration_frac": it_bytes * (it_per_s / world) / 1e9 / HBM_PEAK_GBS},
+            "kernels_ms_per_step": {KIND_NAMES[k]: fam[k][0] / args.steps for k in range(4)},
+            "launches_per_step": {KIND_NAMES[k]: fam[k][1] / args.steps for k in range(4)},
+            "convergence": {"sum_cost": float(red_host[:, 0].sum()), "max_prim": float(red_host[:, 1].max()),
+                            "max_dual": float(red_host[:, 2].max()), "active": float(red_host[:, 3].sum()),
+                            "failed": float(red_host[:, 4].sum())},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, args, B, N, n, m, J, L)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("ISLS_CPU_BASELINE_THREADS", "16")))
+
+
+def cpu_baseline(cfg, args, B, N, n, m, J, L):
+    """The CPU oracle (C port of the reference algorithm, OpenMP over trajectories) timed on this box's host
+    cores on a bounded sample of the same workload.  A reported baseline only -- never the measured path."""
+    from helpers import OracleDriver, problem_arrays
+    from oracle import oracle as orc
+    import isls_problems as P
+
+    kern, lib = orc.load()
+    cores = orc.set_threads(lib, host_cores())
+    sample = args.cpu_sample or min(B, 1024)
+    scfg = P.config2(batch=sample, N=N, seed=0)
+    pa = problem_arrays(scfg, range(sample))
+    d = OracleDriver(kern, pa, rho_u=scfg["rho_u"], relax=scfg["relax"])
+    d.run_c(L, J)                                             # warm-up iteration
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        d.run_c(L, J)                                         # linearise+expand, C driver, accept
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 20:
+            break
+    traj_it_per_s = sample * reps / el
+    return {"value": traj_it_per_s / B, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} outer iterations (J={J}, L={L}) of {sample} trajectories of the same workload, "
+                      f"{el:.1f} s, scaled linearly to batch {B} (trajectories are independent)",
+            "trajectory_iterations_per_s": traj_it_per_s}
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,14 @@ ISLS_API int isls_linearize_f32(const isls_linearize_args *a, void *stream)
 {
     return a ? launch_linearize<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
+ISLS_API int isls_accept_step_f64(const isls_accept_args *a, void *stream)
+{
+    return a ? launch_accept<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_accept_step_f32(const isls_accept_args *a, void *stream)
+{
+    return a ? launch_accept<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
 ISLS_API int isls_reduce_convergence_f64(int32_t B, const void *cost, const void *res, const int32_t *active,
                                          const int32_t *status, void *out5, void *stream)
 {
@@ -149,7 +157,8 @@ ISLS_API const char *isls_error_string(int code)
 ISLS_API int isls_timing_enable(int on)
 {
     g_timing.on = on != 0;
-    for (int k = 0; k < Timing::kKinds; ++k) g_timing.used[k] = 0;
+    if (on)   // (re)start a measurement window; disabling keeps the recorded events readable
+        for (int k = 0; k < Timing::kKinds; ++k) g_timing.used[k] = 0;
     return 0;
 }
 

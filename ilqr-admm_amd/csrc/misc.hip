@@ -199,6 +199,56 @@ template int launch_linearize<double>(const isls_linearize_args &, hipStream_t);
 template int launch_linearize<float>(const isls_linearize_args &, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
+// end of an outer iteration: nominal <- x-step, cost log tail, outer stop rules (isls/isls.py:488-499)
+template <typename T>
+__global__ __launch_bounds__(64) void accept_kernel(int N, int n, int m, const T *xx, const T *xu, const T *cost_new,
+                                                    T *xhat, T *uhat, T *cost, T *hist, int32_t *hist_len,
+                                                    T tol_cost, T tol_osc, int32_t *outer_active)
+{
+    const int b = blockIdx.x;
+    if (outer_active && outer_active[b] == 0) return;
+    const int64_t ox = (int64_t)b * N * n, ou = (int64_t)b * N * m;
+    for (int e = threadIdx.x; e < N * n; e += kWave) xhat[ox + e] = xx[ox + e];
+    for (int e = threadIdx.x; e < N * m; e += kWave) uhat[ou + e] = xu[ou + e];
+    if (threadIdx.x != 0) return;
+    const T prev = cost[b], cur = cost_new[b];
+    cost[b] = cur;
+    bool stop = false;
+    if (tol_cost >= T(0) && fabs(cur - prev) < tol_cost) stop = true;             // isls.py:493
+    if (hist) {
+        T *h = hist + (int64_t)b * 8;
+        int len = hist_len[b];
+        if (len < 8) h[len++] = cur;
+        else {
+            for (int i = 0; i < 7; ++i) h[i] = h[i + 1];
+            h[7] = cur;
+        }
+        hist_len[b] = len;
+        if (!stop && tol_osc >= T(0) && len >= 5) {                               // isls.py:497
+            T a4 = T(0), b4 = T(0);
+            for (int i = len - 4; i < len; ++i) a4 += h[i];
+            for (int i = 0; i < len - 4; ++i) b4 += h[i];
+            if (fabs(a4 / T(4) - b4 / T(len - 4)) < tol_osc) stop = true;
+        }
+    }
+    if (stop && outer_active) outer_active[b] = 0;
+}
+
+template <typename T>
+int launch_accept(const isls_accept_args &a, hipStream_t s)
+{
+    if (a.B < 0 || a.N < 1 || !a.xx || !a.xu || !a.cost_new || !a.xhat || !a.uhat || !a.cost) return ISLS_ERR_ARG;
+    if (a.cost_hist && !a.hist_len) return ISLS_ERR_ARG;
+    if (a.B == 0) return ISLS_OK;
+    hipLaunchKernelGGL((accept_kernel<T>), dim3(a.B), dim3(64), 0, s, (int)a.N, (int)a.n, (int)a.m, (const T *)a.xx,
+                       (const T *)a.xu, (const T *)a.cost_new, (T *)a.xhat, (T *)a.uhat, (T *)a.cost, (T *)a.cost_hist,
+                       a.hist_len, (T)a.tol_cost, (T)a.tol_osc, a.outer_active);
+    return check_launch();
+}
+template int launch_accept<double>(const isls_accept_args &, hipStream_t);
+template int launch_accept<float>(const isls_accept_args &, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
 // out5 = { sum cost, max prim, max dual, #active, #status!=0 } over the local shard (single workgroup)
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_kernel(int B, const T *cost, const T *res, const int32_t *active,

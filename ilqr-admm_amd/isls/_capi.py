@@ -94,6 +94,14 @@ class LinearizeArgs(C.Structure):
                 ("active", C.c_void_p)]
 
 
+class AcceptArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("xx", C.c_void_p), ("xu", C.c_void_p), ("cost_new", C.c_void_p),
+                ("xhat", C.c_void_p), ("uhat", C.c_void_p), ("cost", C.c_void_p),
+                ("cost_hist", C.c_void_p), ("hist_len", C.c_void_p),
+                ("tol_cost", C.c_double), ("tol_osc", C.c_double), ("outer_active", C.c_void_p)]
+
+
 class OuterArgs(C.Structure):
     _fields_ = [("gain", GainArgs), ("ff", FfArgs), ("ro", RolloutArgs), ("admm", AdmmArgs),
                 ("J", C.c_int32), ("skip_gain", C.c_int32), ("log", C.c_void_p), ("outer_active", C.c_void_p)]
@@ -102,7 +110,7 @@ class OuterArgs(C.Structure):
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             ("riccati_gain", "riccati_ff", "rollout_ls", "admm_update", "expand_quadratic", "linearize",
-             "reduce_convergence", "ilqr_admm_outer")] + \
+             "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
            ["isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_read_ms"]
 
 
@@ -363,6 +371,19 @@ class Kernels:
         a.A, a.Bm = _ptr(_dense(A, (B, N, n, n), "A")), _ptr(_dense(Bm, (B, N, n, m), "B"))
         a.active = _ptr(active)
         return self._call("linearize", _sfx(xhat), a, stream)
+
+    def accept_step(self, xx, xu, cost_new, xhat, uhat, cost, cost_hist=None, hist_len=None, tol_cost=-1.0,
+                    tol_osc=-1.0, outer_active=None, stream=None):
+        B, N, n = xx.shape
+        m = xu.shape[2]
+        a = AcceptArgs(B=B, N=N, n=n, m=m, tol_cost=float(tol_cost), tol_osc=float(tol_osc))
+        a.xx, a.xu = _ptr(_dense(xx, (B, N, n), "xx")), _ptr(_dense(xu, (B, N, m), "xu"))
+        a.cost_new = _ptr(_dense(cost_new, (B,), "cost_new"))
+        a.xhat, a.uhat = _ptr(_dense(xhat, (B, N, n), "xhat")), _ptr(_dense(uhat, (B, N, m), "uhat"))
+        a.cost = _ptr(_dense(cost, (B,), "cost"))
+        a.cost_hist, a.hist_len = _ptr(_dense(cost_hist, (B, 8), "cost_hist")), _ptr(hist_len)
+        a.outer_active = _ptr(outer_active)
+        return self._call("accept_step", _sfx(xx), a, stream)
 
     def reduce_convergence(self, cost, res, active, status, out5, stream=None):
         fn = getattr(self.lib, f"{self.prefix}reduce_convergence_{_sfx(out5)}")

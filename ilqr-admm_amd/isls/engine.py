@@ -1,0 +1,240 @@
+"""Device-side state and kernel sequencing of the batched DP-form iLQR-ADMM solver.
+
+`Engine` owns the HBM-resident arrays of B independent trajectories (torch tensors on one MI355X) and
+drives the HIP kernels of csrc/ through the C ABI (include/isls_hip.h).  It is the batched counterpart
+of the state the reference keeps on an `iSLS`/`SLS` object (x_nom, u_nom, A, B, K, k, cost, z, lambda:
+isls/isls_base.py:4-27, isls/base.py:11-24) and of the bodies of `iSLS.ilqr_admm` (isls/isls.py:420-499)
+and `ADMM` (isls/admm.py:6-106).  torch is used for memory and streams only.
+
+HBM layout: every array is [B, N, ...] row-major (trajectory-major), so one trajectory's horizon is a
+contiguous stream (A: N*n*n, K: N*m*n, x: N*n ... elements) that a wavefront slot walks backwards
+(Riccati) or forwards (rollout) with one-step-ahead prefetch; shared tables (LTI A/B, via-point Q, box
+bounds, rho weights) are passed with zero batch/time strides and stay cache-resident.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+
+_LIB = None
+_KERN = None
+
+
+def kernels():
+    """The process-wide binding of csrc/libisls_hip.so (raises if it has not been built)."""
+    global _LIB, _KERN
+    if _KERN is None:
+        _LIB = capi.load_hip_library()
+        _KERN = capi.Kernels(_LIB, prefix="isls_", with_stream=True)
+    return _KERN
+
+
+def library():
+    kernels()
+    return _LIB
+
+
+ALPHAS = 10.0 ** np.linspace(0.0, -5.0, 50)            # line-search grid, isls/isls_base.py:10-11
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Engine:
+    def __init__(self, batch, N, x_dim, u_dim, dtype=torch.float64, device="cuda"):
+        if not torch.cuda.is_available():
+            raise capi.IslsError("isls.Engine needs a HIP device (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        self.kern = kernels()
+        self.B, self.N, self.n, self.m = int(batch), int(N), int(x_dim), int(u_dim)
+        self.dtype, self.device = dtype, torch.device(device)
+        self.sfx = "f64" if dtype == torch.float64 else "f32"
+        B, N, n, m = self.B, self.N, self.n, self.m
+        z = lambda *s: torch.zeros(*s, dtype=dtype, device=self.device)          # noqa: E731
+        zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=self.device)   # noqa: E731
+        # nominal trajectory and its cost
+        self.xhat, self.uhat, self.cost = z(B, N, n), z(B, N, m), z(B)
+        # linearisation and cost expansion
+        self.A, self.Bm = z(B, N, n, n), z(B, N, n, m)
+        self.Cxx, self.Cuu, self.c0x, self.c0u = z(B, N, n, n), z(B, N, m, m), z(B, N, n), z(B, N, m)
+        self.Cux = None
+        # Riccati factors and gains
+        self.K, self.Quu, self.fac, self.Qux, self.k = z(B, N, m, n), z(B, N, m, m), z(B, N, m, m), z(B, N, m, n), z(B, N, m)
+        # x-step result (line-search winner)
+        self.xx, self.xu, self.cost_new = z(B, N, n), z(B, N, m), z(B)
+        self.best, self.status = zi(B), zi(B)
+        # ADMM state
+        self.zx = self.lx = self.zu = self.lu = None
+        self.res, self.res_prev = z(B, 2), torch.full((B, 2), 1e6, dtype=dtype, device=self.device)
+        self.outer_active = torch.ones(B, dtype=torch.int32, device=self.device)
+        self.admm_active = torch.ones(B, dtype=torch.int32, device=self.device)
+        self.out5 = z(5)
+        self.cost_hist, self.hist_len = z(B, 8), zi(B)      # tail of cost_log per trajectory (isls_base.py:85)
+        self.alphas = torch.as_tensor(ALPHAS, dtype=dtype, device=self.device)
+        # problem description
+        self.model = None
+        self.model_par = None
+        self.Qtab = self.ztab = self.seq = self.q_nonzero = None
+        self.u_std = 0.0
+        self.Qr = self.Rr = self.wq = self.wr = None
+        self.x_lo = self.x_hi = self.u_lo = self.u_hi = None
+        self.relax = 1.0
+        self.solve_mode = capi.SOLVE_CHOL
+        self._outer_args = None
+
+    # ---- problem setup ---------------------------------------------------------------------------------
+    def _t(self, x):
+        return torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=self.dtype,
+                               device=self.device).contiguous()
+
+    def set_model(self, model_id, par):
+        """Built-in forward model (ISLS_MODEL_*); par is [P] (shared) or [B,P] (per trajectory)."""
+        self.model, self.model_par = int(model_id), self._t(par)
+        self._outer_args = None
+
+    def set_quadratic_cost(self, zs, Qs, seq, u_std):
+        """Via-point quadratic cost (Base.set_quadratic_cost, isls/base.py:81-89); zs [nvia,n] or [B,nvia,n]."""
+        self.ztab, self.Qtab = self._t(zs), self._t(Qs)
+        seq = np.asarray(seq.cpu() if isinstance(seq, torch.Tensor) else seq).astype(np.int32)
+        self.seq = torch.as_tensor(seq, device=self.device)
+        qnz = (self.Qtab.reshape(-1, self.Qtab.shape[-3], self.n * self.n) != 0).any(-1).any(0).cpu().numpy()
+        self.q_nonzero = torch.as_tensor(qnz[seq].astype(np.int32), device=self.device)
+        self.u_std = float(u_std)
+        self._outer_args = None
+
+    def set_nominal(self, x_nom, u_nom):
+        """nominal_values setter (isls/isls_base.py:80-85): stores the nominal and evaluates its cost."""
+        self.xhat.copy_(self._t(x_nom).expand(self.B, self.N, self.n))
+        self.uhat.copy_(self._t(u_nom).expand(self.B, self.N, self.m))
+        self.evaluate_cost()
+        self.cost_hist.zero_()
+        self.cost_hist[:, 0] = self.cost                  # cost_log = [initial cost]
+        self.hist_len.fill_(1)
+        self.outer_active.fill_(1)
+        self.status.zero_()
+
+    def set_admm(self, rho_x=None, rho_u=None, x_box=None, u_box=None, relax=1.0):
+        """ADMM weights (Base.compute_Rr_Qr, isls/base.py:55-79, dp=True form) and box constraint sets."""
+        B, N, n, m = self.B, self.N, self.n, self.m
+        z = lambda *s: torch.zeros(*s, dtype=self.dtype, device=self.device)      # noqa: E731
+
+        def weights(rho, d):
+            if rho is None:
+                return None
+            if isinstance(rho, (int, float)):
+                return (float(rho) * torch.eye(d, dtype=self.dtype, device=self.device)).reshape(1, d, d)
+            r = self._t(rho)
+            if r.ndim == 2:
+                return r.reshape(1, d, d)
+            return r                                   # [N,d,d] or [B,N,d,d]
+
+        self.Qr = weights(rho_x, n) if x_box is not None else None
+        self.Rr = weights(rho_u, m) if u_box is not None else None
+        if x_box is not None and self.Qr is None:
+            raise ValueError("project_x needs rho_x")
+        if u_box is not None and self.Rr is None:
+            raise ValueError("project_u needs rho_u")
+        # (dx*dx)@Qr precedence (isls/isls.py:473,476): the AL weights are the row sums
+        self.wq = None if self.Qr is None else self.Qr.sum(-1).contiguous()
+        self.wr = None if self.Rr is None else self.Rr.sum(-1).contiguous()
+
+        def bounds(box, d):
+            if box is None:
+                return None, None
+            lo, hi = box
+            lo = self._t(lo) if not isinstance(lo, (int, float)) else torch.full((1, d), float(lo), dtype=self.dtype, device=self.device)
+            hi = self._t(hi) if not isinstance(hi, (int, float)) else torch.full((1, d), float(hi), dtype=self.dtype, device=self.device)
+            if lo.ndim == 1 and lo.numel() == N * d:      # flat [N*d] vectors as the reference's callbacks see them
+                lo, hi = lo.reshape(N, d), hi.reshape(N, d)
+            return lo, hi
+
+        self.x_lo, self.x_hi = bounds(x_box, n)
+        self.u_lo, self.u_hi = bounds(u_box, m)
+        self.zx, self.lx = (z(B, N, n), z(B, N, n)) if x_box is not None else (None, None)
+        self.zu, self.lu = (z(B, N, m), z(B, N, m)) if u_box is not None else (None, None)
+        self.relax = float(relax)
+        self._outer_args = None
+
+    # ---- single kernels -----------------------------------------------------------------------------------
+    def evaluate_cost(self):
+        self.kern.expand_quadratic(self.Qtab, self.ztab, self.seq, self.u_std, self.c0x, self.c0u,
+                                   xhat=self.xhat, uhat=self.uhat, cost=self.cost, stream=_stream_ptr())
+
+    def linearize(self):
+        self.kern.linearize(self.model, self.model_par, self.xhat, self.uhat, self.A, self.Bm,
+                            active=self.outer_active, stream=_stream_ptr())
+
+    def expand(self, with_hessian=True):
+        self.kern.expand_quadratic(self.Qtab, self.ztab, self.seq, self.u_std, self.c0x, self.c0u,
+                                   xhat=self.xhat, uhat=self.uhat,
+                                   Cxx=self.Cxx if with_hessian else None, Cuu=self.Cuu if with_hessian else None,
+                                   Qr=self.Qr, Rr=self.Rr, active=self.outer_active, stream=_stream_ptr())
+
+    def gain(self, active=None):
+        self.kern.riccati_gain(self.A, self.Bm, self.Cxx, self.Cuu, self.K, self.Quu, self.fac, self.Qux,
+                               Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active,
+                               stream=_stream_ptr())
+
+    def feedforward(self, active=None):
+        self.kern.riccati_ff(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
+                             Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx,
+                             zu=self.zu, lu=self.lu, solve_mode=self.solve_mode, active=active, stream=_stream_ptr())
+
+    def rollout(self, L, flags=0, cost_all=None, active=None):
+        self.kern.rollout_ls(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
+                             self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,
+                             cost_new=self.cost_new, cost_all=cost_all, wq=self.wq, wr=self.wr, zx=self.zx,
+                             lx=self.lx, zu=self.zu, lu=self.lu, cost_cur=self.cost, flags=flags,
+                             status=self.status, active=active, q_nonzero=self.q_nonzero, stream=_stream_ptr())
+
+    def admm_update(self, tol_abs, tol_rel, active=None):
+        self.kern.admm_update(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
+                              x_lo=self.x_lo, x_hi=self.x_hi, u_lo=self.u_lo, u_hi=self.u_hi, relax=self.relax,
+                              tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=active,
+                              stream=_stream_ptr())
+
+    # ---- one outer iteration, enqueued by the C driver in one call --------------------------------------------
+    def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None):
+        """Marshal the argument block of isls_ilqr_admm_outer once; it stays valid while buffers are not re-allocated."""
+        K = capi.Kernels
+        gain = K.gain_args(self.A, self.Bm, self.Cxx, self.Cuu, self.K, self.Quu, self.fac, self.Qux, Cux=self.Cux,
+                           solve_mode=self.solve_mode, status=self.status, active=self.admm_active)
+        ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
+                       Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
+                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active)
+        ro = K.rollout_args(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
+                            self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,
+                            cost_new=self.cost_new, wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx, zu=self.zu,
+                            lu=self.lu, cost_cur=self.cost, flags=0, status=self.status, active=self.admm_active,
+                            q_nonzero=self.q_nonzero)
+        admm = K.admm_args(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
+                           x_lo=self.x_lo, x_hi=self.x_hi, u_lo=self.u_lo, u_hi=self.u_hi, relax=self.relax,
+                           tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=self.admm_active)
+        self._outer_args = capi.OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=0)
+        self._outer_args.log = capi._ptr(log)
+        self._outer_args.outer_active = capi._ptr(self.outer_active)
+        self._outer_log = log
+        return self._outer_args
+
+    def run_outer(self):
+        """gain -> J x [ff -> rollout/line-search -> ADMM update] on the current stream (no host sync)."""
+        fn = getattr(library(), f"isls_ilqr_admm_outer_{self.sfx}")
+        fn.restype = ctypes.c_int
+        rc = fn(ctypes.byref(self._outer_args), ctypes.c_void_p(_stream_ptr()))
+        if rc != capi.OK:
+            raise capi.IslsError(f"isls_ilqr_admm_outer_{self.sfx} -> {rc}")
+
+    def accept_x_step(self, tol_cost=-1.0, tol_osc=-1.0):
+        """nominal_values <- last x-step of the ADMM (isls/isls.py:488), cost_log tail and the outer stop
+        rules (isls/isls.py:493-499) for the trajectories still iterating; all on the device."""
+        self.kern.accept_step(self.xx, self.xu, self.cost_new, self.xhat, self.uhat, self.cost,
+                              cost_hist=self.cost_hist, hist_len=self.hist_len, tol_cost=tol_cost, tol_osc=tol_osc,
+                              outer_active=self.outer_active, stream=_stream_ptr())
+
+    def reduce(self):
+        """[sum cost, max prim, max dual, #active, #failed] of the local shard, left on the device."""
+        self.kern.reduce_convergence(self.cost, self.res, self.outer_active, self.status, self.out5, stream=_stream_ptr())
+        return self.out5

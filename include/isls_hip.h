@@ -237,6 +237,28 @@ int isls_linearize_f64(const isls_linearize_args *a, void *stream);
 int isls_linearize_f32(const isls_linearize_args *a, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * End of an outer iteration: nominal_values <- last x-step of the ADMM (isls/isls.py:488; the setter
+ * isls/isls_base.py:80-85 appends the new cost to cost_log) followed by the two outer stop rules
+ * (isls/isls.py:493-499), per trajectory, for the trajectories with outer_active[b] != 0:
+ *   xhat <- xx, uhat <- xu, prev = cost, cost <- cost_new, cost_hist <- push(cost)
+ *   stop if |cost - prev| < tol_cost, or |mean(hist[-4:]) - mean(hist[-8:-4])| < tol_osc (needs >= 5 entries)
+ * cost_hist[B,8] holds the tail of cost_log (oldest first), hist_len[B] its fill (<= 8).  A negative
+ * tolerance disables that rule.  Stopped trajectories get outer_active[b] <- 0.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_accept_args {
+    int32_t B, N, n, m;
+    const void *xx, *xu, *cost_new;
+    void *xhat, *uhat, *cost;
+    void *cost_hist;        /* nullable (then the oscillation rule is skipped) */
+    int32_t *hist_len;
+    double tol_cost, tol_osc;
+    int32_t *outer_active;  /* nullable => every trajectory is updated, no stop rule */
+} isls_accept_args;
+
+int isls_accept_step_f64(const isls_accept_args *a, void *stream);
+int isls_accept_step_f32(const isls_accept_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Convergence reduction over the local batch shard: out[5] = { sum cost, max prim, max dual,
  * #active, #status!=0 } -- the 40-byte payload of the per-iteration RCCL all-reduce.
  * Batched analogue of the scalar tests at isls/isls.py:125-132,493-499 and isls/admm.py:72-85.

@@ -12,6 +12,7 @@ extern "C" {
     int oracle_admm_update_##sfx(const isls_admm_args *a);                                            \
     int oracle_expand_quadratic_##sfx(const isls_expand_args *a);                                     \
     int oracle_linearize_##sfx(const isls_linearize_args *a);                                         \
+    int oracle_accept_step_##sfx(const isls_accept_args *a);                                          \
     int oracle_reduce_convergence_##sfx(int32_t B, const void *cost, const void *res,                 \
                                         const int32_t *active, const int32_t *status, void *out5);    \
     int oracle_ilqr_admm_outer_##sfx(const isls_outer_args *a);

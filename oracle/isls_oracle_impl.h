@@ -575,6 +575,38 @@ int FN(oracle_linearize)(const isls_linearize_args *a)
     return ISLS_OK;
 }
 
+/* End of an outer iteration: nominal <- x-step, cost_log tail, stop rules.  isls/isls.py:488-499,
+ * isls/isls_base.py:80-85. */
+int FN(oracle_accept_step)(const isls_accept_args *a)
+{
+    const int B = a->B, N = a->N, n = a->n, m = a->m;
+    for (int b = 0; b < B; ++b) {
+        if (a->outer_active && !a->outer_active[b]) continue;
+        memcpy((REAL *)a->xhat + (int64_t)b * N * n, (const REAL *)a->xx + (int64_t)b * N * n, sizeof(REAL) * (size_t)N * n);
+        memcpy((REAL *)a->uhat + (int64_t)b * N * m, (const REAL *)a->xu + (int64_t)b * N * m, sizeof(REAL) * (size_t)N * m);
+        REAL *cost = (REAL *)a->cost;
+        const REAL prev = cost[b], cur = ((const REAL *)a->cost_new)[b];
+        cost[b] = cur;
+        int stop = 0;
+        if (a->tol_cost >= 0 && FABS(cur - prev) < (REAL)a->tol_cost) stop = 1;
+        if (a->cost_hist) {
+            REAL *h = (REAL *)a->cost_hist + (int64_t)b * 8;
+            int len = a->hist_len[b];
+            if (len < 8) h[len++] = cur;
+            else { for (int i = 0; i < 7; ++i) h[i] = h[i + 1]; h[7] = cur; }
+            a->hist_len[b] = len;
+            if (!stop && a->tol_osc >= 0 && len >= 5) {
+                REAL a4 = 0, b4 = 0;
+                for (int i = len - 4; i < len; ++i) a4 += h[i];
+                for (int i = 0; i < len - 4; ++i) b4 += h[i];
+                if (FABS(a4 / 4 - b4 / (REAL)(len - 4)) < (REAL)a->tol_osc) stop = 1;
+            }
+        }
+        if (stop && a->outer_active) a->outer_active[b] = 0;
+    }
+    return ISLS_OK;
+}
+
 int FN(oracle_reduce_convergence)(int32_t B, const void *cost, const void *res, const int32_t *active,
                                   const int32_t *status, void *out5)
 {

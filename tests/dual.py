@@ -24,9 +24,11 @@ class DualKernels:
             if self.int_exact and not np.array_equal(h, d):
                 raise AssertionError(f"{name}:{key}: integer mismatch oracle={h[:8]} hip={d[:8]}")
             return
-        scale = max(1.0, float(np.max(np.abs(h))) if h.size else 1.0)
-        both_nan = np.isnan(h) & np.isnan(d)
-        diff = np.where(both_nan, 0.0, np.abs(h - d))
+        fin = np.isfinite(h)
+        scale = max(1.0, float(np.max(np.abs(h[fin]))) if fin.any() else 1.0)
+        same = (np.isnan(h) & np.isnan(d)) | (h == d)               # identical infinities / NaNs agree
+        with np.errstate(invalid="ignore"):
+            diff = np.where(same, 0.0, np.abs(h - d))
         err = float(np.max(diff)) / scale if h.size else 0.0
         if not np.isfinite(err):
             err = float("inf")
@@ -51,7 +53,7 @@ class DualKernels:
                 self._compare(name, k, kw[k], dkw[k])
 
     def __getattr__(self, name):
-        if name in ("riccati_gain", "riccati_ff", "rollout_ls", "admm_update", "expand_quadratic", "linearize"):
+        if name in ("riccati_gain", "riccati_ff", "rollout_ls", "admm_update", "expand_quadratic", "linearize", "accept_step"):
             return lambda *a, **kw: self._dual(name, a, kw)
         raise AttributeError(name)
 

@@ -120,6 +120,33 @@ class OracleDriver:
                               relax=self.relax, tol_abs=tol, tol_rel=tol, res_prev=self.res_prev,
                               active=self.admm_active)
 
+    def run_c(self, L, J, tol=0.0, log=None):
+        """One outer iteration through the library's own driver entry point (`*_ilqr_admm_outer`):
+        linearise + expand, then gain -> J x [ff -> rollout -> update] in one C call, then accept."""
+        pa, K = self.pa, capi.Kernels
+        alphas = ALPHAS[:L].astype(self.dtype)
+        self.linearize_expand()
+        gain = K.gain_args(self.A, self.Bm, self.Cxx, self.Cuu, self.K, self.Quu, self.fac, self.Qux,
+                           status=self.status, active=self.admm_active)
+        ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
+                       Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx,
+                       zu=self.zu, lu=self.lu, active=self.admm_active)
+        ro = K.rollout_args(pa["model"], pa["model_par"], self.K, self.k, self.xhat, self.uhat, alphas,
+                            pa["Qtab"], pa["ztab"], pa["seq"], pa["u_std"], self.xx, self.xu, best=self.best,
+                            cost_new=self.cost_new, wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx,
+                            zu=self.zu, lu=self.lu, cost_cur=self.cost, status=self.status, active=self.admm_active)
+        admm = K.admm_args(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
+                           x_lo=pa.get("x_lo") if self.zx is not None else None,
+                           x_hi=pa.get("x_hi") if self.zx is not None else None,
+                           u_lo=pa["u_lo"] if self.zu is not None else None,
+                           u_hi=pa["u_hi"] if self.zu is not None else None,
+                           relax=self.relax, tol_abs=tol, tol_rel=tol, res_prev=self.res_prev, active=self.admm_active)
+        self._keep = (alphas,)
+        sfx = "f64" if self.dtype == np.float64 else "f32"
+        self.kern.outer(gain, ff, ro, admm, J, sfx, log=log, outer_active=self.outer_active)
+        self.kern.accept_step(self.xx, self.xu, self.cost_new, self.xhat, self.uhat, self.cost,
+                              outer_active=self.outer_active)
+
     def run(self, max_iter, L, J, tol):
         """Returns trace[outer] = dict(K, k[J], xx[J], xu[J], regx[J], regu[J], logs[J,B,2], cost[B], z.., n_inner[B])."""
         B = self.B

@@ -44,14 +44,20 @@ def test_di3d_iterate_once_flags(dual):
     dk = dual()
     d = OracleDriver(dk, pa, project_u=False)
     for it in range(3):
+        # LQ problem: the first Newton step lands on the optimum, afterwards k ~ 0 and the candidates tie
+        # to rounding: the arg-min index / accept bit are then not determined at 1e-16, only the values are
+        dk.int_exact = it == 0
         d.linearize_expand()
         d.gain(), d.ff()
         d.rollout(20, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST, cost_all=np.zeros((9, 20)))
         d.xhat[:], d.uhat[:], d.cost[:] = d.xx, d.xu, d.cost_new
-    # at the optimum no candidate improves: rejection path keeps the nominal
+    # forced rejection: no candidate can beat a current cost of -1 -> the nominal must be kept bit-exactly
+    d.cost[:] = -1.0
+    d.status[:] = 0
     d.linearize_expand()
     d.gain(), d.ff()
     d.rollout(5, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST)
+    assert (d.status & capi.ST_LS_REJECT).all() and np.array_equal(d.xx, d.xhat) and np.array_equal(d.xu, d.uhat)
     _report(dk)
 
 
