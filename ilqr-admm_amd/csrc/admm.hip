@@ -18,7 +18,7 @@ struct AdmmP {
     T *zx, *lx, *zu, *lu;
     View<T> x_lo, x_hi, u_lo, u_hi;
     T *res, *res_prev;
-    int32_t *active;
+    int32_t *active, *iters;
 };
 
 template <typename T>
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void admm_update_kernel(AdmmP<T> p)
         }
         res[0] = prim; res[1] = dual;
         if (prev) { prev[0] = prim; prev[1] = dual; }
+        if (p.iters) p.iters[b] += 1;
     }
 }
 
@@ -98,7 +99,7 @@ int launch_admm(const isls_admm_args &a, hipStream_t s)
     p.xx = (const T *)a.xx; p.xu = (const T *)a.xu;
     p.zx = (T *)a.zx; p.lx = (T *)a.lx; p.zu = (T *)a.zu; p.lu = (T *)a.lu;
     p.x_lo = View<T>(a.x_lo); p.x_hi = View<T>(a.x_hi); p.u_lo = View<T>(a.u_lo); p.u_hi = View<T>(a.u_hi);
-    p.res = (T *)a.res; p.res_prev = (T *)a.res_prev; p.active = a.active;
+    p.res = (T *)a.res; p.res_prev = (T *)a.res_prev; p.active = a.active; p.iters = a.iters;
     hipLaunchKernelGGL((admm_update_kernel<T>), dim3(a.B), dim3(64), 0, s, p);
     return check_launch();
 }

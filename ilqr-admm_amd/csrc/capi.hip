@@ -45,7 +45,7 @@ template <typename T>
 static int outer_iteration(const isls_outer_args &a, hipStream_t s)
 {
     const isls_admm_args &ad = a.admm;
-    int rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, s);
+    int rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, ad.iters, s);
     if (rc != ISLS_OK) return rc;
     if (!a.skip_gain) {
         ScopedTimer tm(0, s);

@@ -29,14 +29,30 @@ struct View {
     __device__ __forceinline__ const T *at(int b, int t) const { return p + (int64_t)b * sb + (int64_t)t * st; }
 };
 
+// Hand-off through LDS between the lanes of ONE wavefront (every recursive kernel here runs
+// single-wave workgroups).  DS instructions of a wave execute in issue order, so a ds_write followed by a
+// ds_read needs no s_barrier and, crucially, no `s_waitcnt vmcnt(0)`: __syncthreads() would drain the
+// global loads that are deliberately kept in flight several steps ahead.  This only pins the compiler's
+// ordering of memory operations (wavefront-scope fences and a wave barrier emit no instructions).
+__device__ __forceinline__ void slot_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Cooperative load of CNT contiguous elements by the G lanes of a slot: lane i gets src[i + G*j].
+// The loads are UNCONDITIONAL (index clamped into the segment; callers pass a valid trajectory's pointer
+// for idle lanes) and their results are not touched here: a predicate would cost a branch per load and
+// any arithmetic on the result would force an s_waitcnt right behind the load, defeating the prefetch
+// ring.  Surplus elements are simply never written to LDS (coop_put checks the range).
 template <int CNT, int G, typename T>
-__device__ __forceinline__ void coop_load(const T *src, T (&r)[(CNT + G - 1) / G], int i, bool ok)
+__device__ __forceinline__ void coop_load(const T *src, T (&r)[(CNT + G - 1) / G], int i, bool /*ok*/)
 {
 #pragma unroll
     for (int j = 0; j < (CNT + G - 1) / G; ++j) {
         const int e = i + G * j;
-        r[j] = (ok && e < CNT) ? src[e] : T(0);
+        r[j] = src[e < CNT ? e : CNT - 1];
     }
 }
 template <int CNT, int G, typename T>
@@ -140,7 +156,7 @@ template <typename T> int launch_reduce(int32_t B, const void *cost, const void 
                                         const int32_t *status, void *out5, hipStream_t s);
 template <typename T> int launch_outer_begin(int32_t B, int32_t N, int32_t n, int32_t m, int32_t *admm_active,
                                              const int32_t *outer_active, void *lx, void *lu, void *res_prev,
-                                             hipStream_t s);
+                                             int32_t *iters, hipStream_t s);
 
 inline int check_launch()
 {

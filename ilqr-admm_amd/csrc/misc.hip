@@ -294,12 +294,14 @@ template int launch_reduce<float>(int32_t, const void *, const void *, const int
 // previous residual norms <- 1e6 (admm.py:25-26), for the trajectories still iterating.
 template <typename T>
 __global__ __launch_bounds__(64) void outer_begin_kernel(int N, int n, int m, int32_t *admm_active,
-                                                         const int32_t *outer_active, T *lx, T *lu, T *res_prev)
+                                                         const int32_t *outer_active, T *lx, T *lu, T *res_prev,
+                                                         int32_t *iters)
 {
     const int b = blockIdx.x;
     const bool act = outer_active == nullptr || outer_active[b] != 0;
     if (threadIdx.x == 0 && admm_active) admm_active[b] = act ? 1 : 0;
     if (!act) return;
+    if (threadIdx.x == 0 && iters) iters[b] = 0;
     if (lx) for (int e = threadIdx.x; e < N * n; e += kWave) lx[(int64_t)b * N * n + e] = T(0);
     if (lu) for (int e = threadIdx.x; e < N * m; e += kWave) lu[(int64_t)b * N * m + e] = T(0);
     if (res_prev && threadIdx.x < 2) res_prev[(int64_t)b * 2 + threadIdx.x] = T(1e6);
@@ -307,14 +309,14 @@ __global__ __launch_bounds__(64) void outer_begin_kernel(int N, int n, int m, in
 
 template <typename T>
 int launch_outer_begin(int32_t B, int32_t N, int32_t n, int32_t m, int32_t *admm_active, const int32_t *outer_active,
-                       void *lx, void *lu, void *res_prev, hipStream_t s)
+                       void *lx, void *lu, void *res_prev, int32_t *iters, hipStream_t s)
 {
     if (B <= 0) return ISLS_OK;
     hipLaunchKernelGGL((outer_begin_kernel<T>), dim3(B), dim3(64), 0, s, (int)N, (int)n, (int)m, admm_active, outer_active,
-                       (T *)lx, (T *)lu, (T *)res_prev);
+                       (T *)lx, (T *)lu, (T *)res_prev, iters);
     return check_launch();
 }
-template int launch_outer_begin<double>(int32_t, int32_t, int32_t, int32_t, int32_t *, const int32_t *, void *, void *, void *, hipStream_t);
-template int launch_outer_begin<float>(int32_t, int32_t, int32_t, int32_t, int32_t *, const int32_t *, void *, void *, void *, hipStream_t);
+template int launch_outer_begin<double>(int32_t, int32_t, int32_t, int32_t, int32_t *, const int32_t *, void *, void *, void *, int32_t *, hipStream_t);
+template int launch_outer_begin<float>(int32_t, int32_t, int32_t, int32_t, int32_t *, const int32_t *, void *, void *, void *, int32_t *, hipStream_t);
 
 }  // namespace isls

@@ -10,11 +10,18 @@
 //     M_i  = sum_k S_i[k]   * [A B][k,:]        (row i of the stack, n FMAs x (n+m))
 // so lanes i<n end up with a row of Qxx, lanes i>=n with a row of [Qux Quu].  V, [A B] and the small
 // factors live in the slot's LDS record and are read back as broadcasts (all lanes of a slot read the
-// same word) or as the lane's own column.  A_t, B_t (and C_t rows) of step t-1 are fetched from HBM
-// while step t is being computed (register staging), so the sequential chain only waits on LDS.
+// same word) or as the lane's own column.
+//
+// The recursion is sequential in t, so HBM latency cannot be hidden by the dependent chain itself:
+// every lane keeps a RING of D steps of operands in flight in registers (loads for step t-D are issued
+// while step t is computed; the compiler's counted s_waitcnt vmcnt lets the oldest entry land while the
+// younger ones are still travelling).
 #include "isls_common.hpp"
 
 namespace isls {
+
+constexpr int kGainDepth = 4;   // steps of A,B,C in flight per lane in the gain pass
+constexpr int kFfDepth = 4;     // steps of operands in flight per lane in the feed-forward pass
 
 // ================================================================================================
 // Gain pass
@@ -28,7 +35,7 @@ struct GainP {
     const int32_t *active;
 };
 
-template <typename T, int NX, int NU>
+template <typename T, int NX, int NU, int D>
 __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
@@ -43,16 +50,17 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     const bool inslot = s < TPW;
     const bool valid = inslot && b < p.B && (p.active == nullptr || p.active[b] != 0);
     const int N = p.N;
+    const int bb = valid ? b : 0;
     T *rec = lds + (inslot ? s : TPW - 1) * SLOT;
     T *Vs = rec + V_OFF, *ABs = rec + AB_OFF, *Qs = rec + Q_OFF, *Ks = rec + K_OFF;
     const bool xl = i < NX;                                   // lane owns a row of Qxx
     const int a_row = xl ? 0 : i - NX;                        // row of [Qux Quu] for u-lanes
-    const int64_t bN = (int64_t)(valid ? b : 0) * N;
+    const int64_t bN = (int64_t)bb * N;
 
     // ---- terminal step: K[N-1] = 0 (isls.py:245), V = Cxx[N-1] (isls.py:251/257) -----------------
     {
         T r[JA];
-        coop_load<NX * NX, G>(p.Cxx.at(valid ? b : 0, N - 1), r, i, valid);
+        coop_load<NX * NX, G>(p.Cxx.at(bb, N - 1), r, i, valid);
         coop_put<NX * NX, G>(Vs, r, i, valid);
         if (valid) {
             const int64_t o = bN + (N - 1);
@@ -69,46 +77,48 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         }
     }
 
-    // ---- register staging of step t operands ------------------------------------------------------
-    T ra[JA], rb[JB], crow[W];
-    auto fetch = [&](int t) {
-        const int bb = valid ? b : 0;
-        coop_load<NX * NX, G>(p.A.at(bb, t), ra, i, valid);
-        coop_load<NX * NU, G>(p.Bm.at(bb, t), rb, i, valid);
-        // row i of the cost Hessian stack: [Cxx[i,:]] or [Cux[a,:] Cuu[a,:]]
-        if (xl) {
-            const T *c = p.Cxx.at(bb, t) + i * NX;
-#pragma unroll
-            for (int j = 0; j < W; ++j) crow[j] = (valid && j < NX) ? c[j < NX ? j : 0] : T(0);
-        } else {
-            const T *cu = p.Cuu.at(bb, t) + a_row * NU;
-            const T *cx = p.Cux.p ? p.Cux.at(bb, t) + a_row * NX : nullptr;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) crow[j] = (valid && cx) ? cx[j] : T(0);
-#pragma unroll
-            for (int j = 0; j < NU; ++j) crow[NX + j] = valid ? cu[j] : T(0);
-        }
+    // ---- register ring: operands of D steps in flight ------------------------------------------------
+    const bool has_cux = p.Cux.p != nullptr;
+    struct Stage {
+        T ra[JA], rb[JB], crow[W];
     };
-    if (N >= 2) fetch(N - 2);
+    Stage ring[D];
+    auto fetch = [&](int t, Stage &g) {
+        coop_load<NX * NX, G>(p.A.at(bb, t), g.ra, i, valid);
+        coop_load<NX * NU, G>(p.Bm.at(bb, t), g.rb, i, valid);
+        // row i of the cost Hessian stack: [Cxx[i,:]] or [Cux[a,:] Cuu[a,:]]
+        // Raw, unconditional loads through per-lane pointers (no branch, no arithmetic on the results here).
+        // x-lanes: columns >= NX of crow are never used; u-lanes without a Cux array read Cxx instead and
+        // the step zeroes that part when it consumes the row.
+        const T *cl = xl ? p.Cxx.at(bb, t) + i * NX : (has_cux ? p.Cux.at(bb, t) + a_row * NX : p.Cxx.at(bb, t));
+        const T *cr = xl ? cl : p.Cuu.at(bb, t) + a_row * NU;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) g.crow[j] = cl[j];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) g.crow[NX + j] = cr[j];
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        fetch(N - 2 - d > 0 ? N - 2 - d : 0, ring[d]);          // unconditional (clamped): exact vmcnt bookkeeping
     bool pd_ok = true;
 
-    for (int t = N - 2; t >= 0; --t) {
+    auto step = [&](int t, Stage &g) {
         // stage [A_t B_t] into the record: row k = [A[k,:] B[k,:]]
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
             const int e = i + G * j;
-            if (valid && e < NX * NX) ABs[(e / NX) * W + (e % NX)] = ra[j];
+            if (valid && e < NX * NX) ABs[(e / NX) * W + (e % NX)] = g.ra[j];
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const int e = i + G * j;
-            if (valid && e < NX * NU) ABs[(e / NU) * W + NX + (e % NU)] = rb[j];
+            if (valid && e < NX * NU) ABs[(e / NU) * W + NX + (e % NU)] = g.rb[j];
         }
         T c_now[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) c_now[j] = crow[j];
-        __syncthreads();                                       // (a) ABs, Vs visible to the slot
-        if (t > 0) fetch(t - 1);                               // HBM loads for the next step fly during compute
+        for (int j = 0; j < W; ++j) c_now[j] = (j < NX && !xl && !has_cux) ? T(0) : g.crow[j];   // Cux absent -> 0
+        slot_sync();                                          // (a) ABs, Vs visible to the slot
+        fetch(t - D > 0 ? t - D : 0, g);                       // refill this ring entry (clamped, unconditional)
 
         // (1) S = row i of [A B]'V
         T S[NX];
@@ -136,18 +146,17 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 #pragma unroll
             for (int c = 0; c < W; ++c) Qs[a_row * W + c] = M[c];
         }
-        __syncthreads();                                       // (b)
+        slot_sync();                                          // (b)
 
         // (4) factor Quu (redundantly in every lane), solve for column i of K
-        T Quu[NU][NU], U[NU][NU], rd[NU], rhs[NU], Kc[NU];
+        T Quu[NU][NU], U[NU][NU], rd[NU], rhs[NU], Kc[NU], inv[NU][NU];
 #pragma unroll
         for (int r = 0; r < NU; ++r) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) { Quu[r][c] = Qs[r * W + NX + c]; U[r][c] = T(0); }
+            for (int c = 0; c < NU; ++c) { Quu[r][c] = Qs[r * W + NX + c]; U[r][c] = T(0); inv[r][c] = T(0); }
             rhs[r] = Qs[r * W + (xl ? i : 0)];                 // column i of Qux
         }
         pd_ok = chol_upper<NU>(Quu, U, rd) && pd_ok;
-        T inv[NU][NU];
         if (p.mode == ISLS_SOLVE_CHOL) {
             T x[NU];
             chol_solve<NU>(U, rd, rhs, x);                     // sol = -solve(Quu, Qux)  (isls.py:296)
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                 }
             }
         }
-        __syncthreads();                                       // (c) Ks visible
+        slot_sync();                                          // (c) Ks visible
 
         // (5) V row i = Qxx + (K'Quu)K + Qux'K + K'Qux   (isls.py:300 / sls.py:153), x-lanes only
         if (xl) {
@@ -231,7 +240,18 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                 if (valid) Vs[i * NX + j] = vn;
             }
         }
+    };
+
+    // full groups of D steps run branch-free (every VMEM op of the steady state is unconditional, so the
+    // compiler's vmcnt bookkeeping is exact and D steps of loads really stay in flight); then the remainder
+    int tb = N - 2;
+    for (; tb - (D - 1) >= 0; tb -= D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) step(tb - d, ring[d]);
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (tb - d >= 0) step(tb - d, ring[d]);
     if (valid && i == 0 && !pd_ok && p.status) atomicOr(&p.status[b], ISLS_ST_NOT_PD);
 }
 
@@ -247,11 +267,11 @@ int launch_gain(const isls_gain_args &a, hipStream_t s)
     p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.Cxx = View<T>(a.Cxx); p.Cuu = View<T>(a.Cuu); p.Cux = View<T>(a.Cux);
     p.K = (T *)a.K; p.Quu = (T *)a.Quu; p.fac = (T *)a.fac; p.Qux = (T *)a.Qux;
     p.status = a.status; p.active = a.active;
-#define CALL(NX_, NU_)                                                                        \
-    {                                                                                         \
-        constexpr int TPW = kWave / (NX_ + NU_);                                              \
-        const int grid = (a.B + TPW - 1) / TPW;                                               \
-        hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_>), dim3(grid), dim3(64), 0, s, p); \
+#define CALL(NX_, NU_)                                                                                     \
+    {                                                                                                      \
+        constexpr int TPW = kWave / (NX_ + NU_);                                                           \
+        const int grid = (a.B + TPW - 1) / TPW;                                                            \
+        hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth>), dim3(grid), dim3(64), 0, s, p);  \
     }
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
@@ -273,7 +293,7 @@ struct FfP {
     const int32_t *active;
 };
 
-template <typename T, int NX, int NU>
+template <typename T, int NX, int NU, int D>
 __global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
@@ -300,87 +320,94 @@ __global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
     const bool hasx = p.Qr.p != nullptr, hasu = p.Rr.p != nullptr;
     const bool hasreg = xl ? hasx : hasu;
 
-    // per-step staged operands
-    T ra[JA], rb[JB], rk[JK], rq[JK], ruu[JU], rf[JU];
-    T c0, dreg, rrow[NX];                                  // own gradient entry, own reg difference, own Qr/Rr row
-    auto fetch = [&](int t, bool factors) {
+    // per-step staged operands: a ring of D steps in flight (this pass is HBM-bound: ~1 KB per step and
+    // trajectory against ~130 FMAs, so the loads must run several steps ahead of the recursion)
+    struct Stage {
+        T ra[JA], rb[JB], rk[JK], rq[JK], ruu[JU], rf[JU];
+        T c0, hv, zv, lv, rrow[NX];                        // own gradient entry, own xhat/z/lambda entry, own Qr/Rr row
+    };
+    Stage ring[D];
+    auto fetch = [&](int t, bool factors, Stage &g) {
         const int64_t o = bN + t;
         if (factors) {
-            coop_load<NX * NX, G>(p.A.at(bb, t), ra, i, valid);
-            coop_load<NX * NU, G>(p.Bm.at(bb, t), rb, i, valid);
-            coop_load<NU * NX, G>(p.K + o * NU * NX, rk, i, valid);
-            coop_load<NU * NX, G>(p.Qux + o * NU * NX, rq, i, valid);
-            coop_load<NU * NU, G>(p.Quu + o * NU * NU, ruu, i, valid);
-            coop_load<NU * NU, G>(p.fac + o * NU * NU, rf, i, valid);
+            coop_load<NX * NX, G>(p.A.at(bb, t), g.ra, i, valid);
+            coop_load<NX * NU, G>(p.Bm.at(bb, t), g.rb, i, valid);
+            coop_load<NU * NX, G>(p.K + o * NU * NX, g.rk, i, valid);
+            coop_load<NU * NX, G>(p.Qux + o * NU * NX, g.rq, i, valid);
+            coop_load<NU * NU, G>(p.Quu + o * NU * NU, g.ruu, i, valid);
+            coop_load<NU * NU, G>(p.fac + o * NU * NU, g.rf, i, valid);
         }
-        c0 = valid ? (xl ? p.c0x.at(bb, t)[i] : p.c0u.at(bb, t)[iu]) : T(0);
-        dreg = T(0);
+        // raw, unconditional loads only (see coop_load): own gradient entry, own xhat/z/lambda entry and own
+        // row of Qr/Rr, all through per-lane pointers; masking and arithmetic happen when the step consumes them
+        g.c0 = xl ? p.c0x.at(bb, t)[i] : p.c0u.at(bb, t)[iu];
+        if (hasreg) {
+            const int64_t e = xl ? o * NX + i : o * NU + iu;
+            g.zv = (xl ? p.zx : p.zu)[e];
+            g.lv = (xl ? p.lx : p.lu)[e];
+            const T *hat = xl ? p.xhat : p.uhat;
+            g.hv = hat ? hat[e] : T(0);
+            const T *q = xl ? p.Qr.at(bb, t) + i * NX : p.Rr.at(bb, t) + iu * NU;
+            const int lim = xl ? NX : NU;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) rrow[j] = T(0);
-        if (valid && hasreg) {
-            if (xl) {
-                const T xh = p.xhat ? p.xhat[o * NX + i] : T(0);
-                dreg = xh - (p.zx[o * NX + i] - p.lx[o * NX + i]);
-                const T *q = p.Qr.at(bb, t) + i * NX;
+            for (int j = 0; j < NX; ++j) g.rrow[j] = q[j < lim ? j : lim - 1];
+        } else {
+            g.hv = g.zv = g.lv = T(0);
 #pragma unroll
-                for (int j = 0; j < NX; ++j) rrow[j] = q[j];
-            } else {
-                const T uh = p.uhat ? p.uhat[o * NU + iu] : T(0);
-                dreg = uh - (p.zu[o * NU + iu] - p.lu[o * NU + iu]);
-                const T *q = p.Rr.at(bb, t) + iu * NU;
-#pragma unroll
-                for (int j = 0; j < NU; ++j) rrow[j] = q[j];
-            }
+            for (int j = 0; j < NX; ++j) g.rrow[j] = T(0);
         }
     };
     // cx_i / cu_i = c0 + 2 * (row of Qr/Rr) . d       (isls/sls.py:132-137; O2 of SURVEY 8c)
     auto reg_grad = [&](T c0v, const T (&row)[NX]) -> T {
+        // one fully unrolled loop with a select (two loops of different trip counts under a lane-dependent
+        // branch get merged into a runtime-trip-count loop, which sends `row` to scratch memory)
+        const int off = xl ? 0 : NX, lim = xl ? NX : NU;
         T sacc = T(0);
-        if (xl) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) sacc += row[j] * Ds[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < NU; ++j) sacc += row[j] * Ds[NX + j];
+        for (int j = 0; j < NX; ++j) {
+            const T dj = Ds[off + j];                          // j >= lim reads a neighbour word, discarded below
+            sacc += (j < lim) ? row[j] * dj : T(0);
         }
         return hasreg ? c0v + T(2) * sacc : c0v;
     };
 
     // ---- terminal step: v = cx[N-1], k[N-1] = 0 ------------------------------------------------------
-    fetch(N - 1, false);
-    if (valid) Ds[i] = dreg;
-    __syncthreads();
     {
-        const T cterm = reg_grad(c0, rrow);
+        Stage term;
+        fetch(N - 1, false, term);
+        if (valid) Ds[i] = hasreg ? term.hv - (term.zv - term.lv) : T(0);
+        slot_sync();   
+        const T cterm = reg_grad(term.c0, term.rrow);
         if (valid && xl) Vs[i] = cterm;
         if (valid && !xl) p.k[(bN + N - 1) * NU + iu] = T(0);
     }
-    if (N >= 2) fetch(N - 2, true);
-    __syncthreads();
+    slot_sync();   
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        fetch(N - 2 - d > 0 ? N - 2 - d : 0, true, ring[d]);    // unconditional (clamped): exact vmcnt bookkeeping
 
-    for (int t = N - 2; t >= 0; --t) {
+    auto step = [&](int t, Stage &g) {
         // stage the prefetched operands of step t
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
             const int e = i + G * j;
-            if (valid && e < NX * NX) ABs[(e / NX) * W + (e % NX)] = ra[j];
+            if (valid && e < NX * NX) ABs[(e / NX) * W + (e % NX)] = g.ra[j];
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const int e = i + G * j;
-            if (valid && e < NX * NU) ABs[(e / NU) * W + NX + (e % NU)] = rb[j];
+            if (valid && e < NX * NU) ABs[(e / NU) * W + NX + (e % NU)] = g.rb[j];
         }
-        coop_put<NU * NX, G>(Ks, rk, i, valid);
-        coop_put<NU * NX, G>(Quxs, rq, i, valid);
-        coop_put<NU * NU, G>(Quus, ruu, i, valid);
-        coop_put<NU * NU, G>(Facs, rf, i, valid);
-        if (valid) Ds[i] = dreg;
-        const T c0_now = c0;
+        coop_put<NU * NX, G>(Ks, g.rk, i, valid);
+        coop_put<NU * NX, G>(Quxs, g.rq, i, valid);
+        coop_put<NU * NU, G>(Quus, g.ruu, i, valid);
+        coop_put<NU * NU, G>(Facs, g.rf, i, valid);
+        if (valid) Ds[i] = hasreg ? g.hv - (g.zv - g.lv) : T(0);     // xhat - (z - lambda)
+        const T c0_now = g.c0;
         T row_now[NX];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) row_now[j] = rrow[j];
-        __syncthreads();                                       // (a) record + v of the previous step visible
-        if (t > 0) fetch(t - 1, true);
+        for (int j = 0; j < NX; ++j) row_now[j] = g.rrow[j];
+        slot_sync();                                          // (a) record + v of the previous step visible
+        fetch(t - D > 0 ? t - D : 0, true, g);                 // refill this ring entry (clamped, unconditional)
 
         // q_i = c_i + ([A B]' v)_i        (isls.py:285-286)
         const T ci = reg_grad(c0_now, row_now);
@@ -389,7 +416,7 @@ __global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
         for (int k = 0; k < NX; ++k) sacc += ABs[k * W + i] * Vs[k];
         const T qi = ci + sacc;
         if (valid && !xl) Qus[iu] = qi;
-        __syncthreads();                                       // (b) qu visible
+        slot_sync();                                          // (b) qu visible
 
         // k_t = -Quu^{-1} qu  (every lane), then v_i for x-lanes
         T qu[NU], kt[NU];
@@ -433,14 +460,26 @@ __global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
             vnew = (p.mode == ISLS_SOLVE_CHOL) ? ((qi + t_kqu) + t_kquuk) + t_quxk      // isls.py:302
                                                : ((qi + t_quxk) + t_kqu) + t_kquuk;     // sls.py:200
         } else if (valid) {
-            T kv = kt[0];
+            // one predicated store per row (a select chain over kt[] gets turned into a runtime-indexed
+            // private array, i.e. scratch memory)
 #pragma unroll
-            for (int r = 1; r < NU; ++r) kv = (iu == r) ? kt[r] : kv;
-            p.k[(bN + t) * NU + iu] = kv;
+            for (int r = 0; r < NU; ++r)
+                if (iu == r) p.k[(bN + t) * NU + r] = kt[r];
         }
-        __syncthreads();                                       // (c) everyone has read v
+        slot_sync();                                          // (c) everyone has read v
         if (valid && xl) Vs[i] = vnew;
+    };
+
+    // full groups of D steps run branch-free (every VMEM op of the steady state is unconditional, so the
+    // compiler's vmcnt bookkeeping is exact and D steps of loads really stay in flight); then the remainder
+    int tb = N - 2;
+    for (; tb - (D - 1) >= 0; tb -= D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) step(tb - d, ring[d]);
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (tb - d >= 0) step(tb - d, ring[d]);
 }
 
 template <typename T>
@@ -460,11 +499,11 @@ int launch_ff(const isls_ff_args &a, hipStream_t s)
     p.zx = (const T *)a.zx; p.lx = (const T *)a.lx; p.zu = (const T *)a.zu; p.lu = (const T *)a.lu;
     p.K = (const T *)a.K; p.Quu = (const T *)a.Quu; p.fac = (const T *)a.fac; p.Qux = (const T *)a.Qux;
     p.k = (T *)a.k; p.active = a.active;
-#define CALL(NX_, NU_)                                                                      \
-    {                                                                                       \
-        constexpr int TPW = kWave / (NX_ + NU_);                                            \
-        const int grid = (a.B + TPW - 1) / TPW;                                             \
-        hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_>), dim3(grid), dim3(64), 0, s, p); \
+#define CALL(NX_, NU_)                                                                                 \
+    {                                                                                                  \
+        constexpr int TPW = kWave / (NX_ + NU_);                                                       \
+        const int grid = (a.B + TPW - 1) / TPW;                                                        \
+        hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth>), dim3(grid), dim3(64), 0, s, p);  \
     }
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL

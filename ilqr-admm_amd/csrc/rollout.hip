@@ -99,9 +99,12 @@ struct Model<T, 4, 2, ISLS_MODEL_CAR> {        // car-simple [x, y, theta, v]  (
     }
 };
 
+constexpr int kRolloutDepth = 6;   // steps of record elements in flight per lane
+
 template <typename T, int NX, int NU, int MODEL>
 __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
 {
+    constexpr int D = kRolloutDepth;
     // record layout (doubles): K | xh | rx | wq | k | uh | ru | wr
     constexpr int O_K = 0, O_XH = O_K + NU * NX, O_RX = O_XH + NX, O_WQ = O_RX + NX, O_KK = O_WQ + NX,
                   O_UH = O_KK + NU, O_RU = O_UH + NU, O_WR = O_RU + NU, REC = O_WR + NU;
@@ -143,23 +146,34 @@ __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
         else if (e < O_WR) { if (has_wr) { pa[j] = p.zu + bN * NU + (e - O_RU); pb[j] = p.lu + bN * NU + (e - O_RU); stp[j] = NU; } }
         else { if (has_wr) { pa[j] = p.wr.at(bb, 0) + (e - O_WR); stp[j] = (int)p.wr.st; } }
     }
-    T stage[MAXJ];
-    auto fetch = [&](int t) {
+    // ring of D steps of record elements in flight per lane (HBM latency >> one step of math)
+    // Loads are raw and unconditional (absent elements point at K[b,0,0,0], a valid word, with stride 0) so
+    // that no branch and no arithmetic sits behind a load; z - lambda and the masking happen in put().
+    struct Stage {
+        T a[MAXJ], b[MAXJ];
+    };
+    bool has_a[MAXJ], has_b[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        has_a[j] = pa[j] != nullptr;
+        has_b[j] = pb[j] != nullptr;
+        if (!has_a[j]) { pa[j] = p.K + bN * NU * NX; stp[j] = 0; }
+        if (!has_b[j]) pb[j] = pa[j];
+    }
+    auto fetch = [&](int t, Stage &g) {
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            T v = T(0);
-            if (pa[j]) {
-                v = pa[j][(int64_t)t * stp[j]];
-                if (pb[j]) v = v - pb[j][(int64_t)t * stp[j]];      // z - lambda
-            }
-            stage[j] = v;
+            const int64_t o = (int64_t)t * stp[j];
+            g.a[j] = pa[j][o];
+            if (has_b[j]) g.b[j] = pb[j][o];                    // only the z/lambda pairs carry a second word
         }
     };
-    auto put = [&](T *rec) {
+    auto put = [&](T *rec, const Stage &g) {
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int e = c + GL * j;
-            if (valid && e < REC) rec[e] = stage[j];
+            const T v = has_a[j] ? (has_b[j] ? g.a[j] - g.b[j] : g.a[j]) : T(0);      // z - lambda
+            if (valid && e < REC) rec[e] = v;
         }
     };
 
@@ -192,12 +206,15 @@ __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
 #pragma unroll
         for (int j = 0; j < NX; ++j) x[j] = x_init[j];
         cst = T(0); cu = T(0); ag = T(0);
-        fetch(0);
-        for (int t = 0; t < N; ++t) {
+        Stage ring[D] = {};
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            fetch(d < N ? d : N - 1, ring[d]);                 // unconditional (clamped): exact vmcnt bookkeeping
+        auto step = [&](int t, Stage &g) {
             T *rec = recs + (t & 1) * REC;
-            put(rec);
-            __syncthreads();                                   // record(t) (and out(t-1)) visible
-            if (t + 1 < N) fetch(t + 1);
+            put(rec, g);
+            slot_sync();                                      // record(t) (and out(t-1)) visible
+            fetch(t + D < N ? t + D : N - 1, g);               // refill this ring entry (clamped, unconditional)
             if (!SEARCH && t > 0) stream_out(t - 1);
             // u = (x - xhat) K' + alpha k + uhat            (isls.py:328-329)
             T u[NU];
@@ -243,8 +260,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
             model.step(x, u, xn);                              // x = f(x, u)   (isls.py:332)
 #pragma unroll
             for (int j = 0; j < NX; ++j) x[j] = xn[j];
+        };
+        int tb = 0;
+        for (; tb + D <= N; tb += D) {                         // full groups: branch-free, exact vmcnt bookkeeping
+#pragma unroll
+            for (int d = 0; d < D; ++d) step(tb + d, ring[d]);
         }
-        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (tb + d < N) step(tb + d, ring[d]);
+        slot_sync();   
         if (!SEARCH) stream_out(N - 1);
     };
 
@@ -255,7 +280,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
     const T plain = cst + cu;                                  // sum over x, then += sum over u (sls_base.py:33-39)
     const T aug = plain + ag;
     if (cand) { c_aug[c] = aug; c_pln[c] = plain; }
-    __syncthreads();
+    slot_sync();   
     // first arg-min with numpy's NaN semantics; optional costs[isnan] = 1e5 (isls.py:362)
     const bool nan_rule = (p.flags & ISLS_RO_NAN_TO_1E5) != 0;
     int ind = 0;
@@ -283,7 +308,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
     }
     // ---- winner pass ----------------------------------------------------------------------------------
     const T alpha_w = absolute ? T(1) : p.alphas[ind];
-    __syncthreads();
+    slot_sync();   
     roll(std::false_type{}, alpha_w, !accept, cst, cu, ag);
 }
 

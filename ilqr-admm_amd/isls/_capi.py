@@ -72,7 +72,7 @@ class AdmmArgs(C.Structure):
                 ("xx", C.c_void_p), ("xu", C.c_void_p),
                 ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
                 ("x_lo", View), ("x_hi", View), ("u_lo", View), ("u_hi", View),
-                ("res", C.c_void_p), ("res_prev", C.c_void_p), ("active", C.c_void_p)]
+                ("res", C.c_void_p), ("res_prev", C.c_void_p), ("active", C.c_void_p), ("iters", C.c_void_p)]
 
 
 class ExpandArgs(C.Structure):
@@ -311,7 +311,7 @@ class Kernels:
 
     @staticmethod
     def admm_args(xx, xu, res, zx=None, lx=None, zu=None, lu=None, x_lo=None, x_hi=None, u_lo=None, u_hi=None,
-                  relax=1.0, tol_abs=0.0, tol_rel=0.0, res_prev=None, active=None):
+                  relax=1.0, tol_abs=0.0, tol_rel=0.0, res_prev=None, active=None, iters=None):
         B, N, n = xx.shape
         m = xu.shape[2]
         a = AdmmArgs(B=B, N=N, n=n, m=m, relax=float(relax), tol_abs=float(tol_abs), tol_rel=float(tol_rel))
@@ -323,7 +323,7 @@ class Kernels:
         a.x_lo, a.x_hi = make_view(x_lo, B, N, (n,), "x_lo"), make_view(x_hi, B, N, (n,), "x_hi")
         a.u_lo, a.u_hi = make_view(u_lo, B, N, (m,), "u_lo"), make_view(u_hi, B, N, (m,), "u_hi")
         a.res, a.res_prev = _ptr(_dense(res, (B, 2), "res")), _ptr(_dense(res_prev, (B, 2), "res_prev"))
-        a.active = _ptr(active)
+        a.active, a.iters = _ptr(active), _ptr(iters)
         return a
 
     # -- kernels -------------------------------------------------------------------------------------

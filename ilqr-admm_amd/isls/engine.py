@@ -71,6 +71,7 @@ class Engine:
         self.res, self.res_prev = z(B, 2), torch.full((B, 2), 1e6, dtype=dtype, device=self.device)
         self.outer_active = torch.ones(B, dtype=torch.int32, device=self.device)
         self.admm_active = torch.ones(B, dtype=torch.int32, device=self.device)
+        self.admm_iters = zi(B)                              # executed ADMM iterations of the current outer iteration
         self.out5 = z(5)
         self.cost_hist, self.hist_len = z(B, 8), zi(B)      # tail of cost_log per trajectory (isls_base.py:85)
         self.alphas = torch.as_tensor(ALPHAS, dtype=dtype, device=self.device)
@@ -194,7 +195,7 @@ class Engine:
         self.kern.admm_update(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
                               x_lo=self.x_lo, x_hi=self.x_hi, u_lo=self.u_lo, u_hi=self.u_hi, relax=self.relax,
                               tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=active,
-                              stream=_stream_ptr())
+                              iters=self.admm_iters, stream=_stream_ptr())
 
     # ---- one outer iteration, enqueued by the C driver in one call --------------------------------------------
     def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None):
@@ -212,7 +213,8 @@ class Engine:
                             q_nonzero=self.q_nonzero)
         admm = K.admm_args(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
                            x_lo=self.x_lo, x_hi=self.x_hi, u_lo=self.u_lo, u_hi=self.u_hi, relax=self.relax,
-                           tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=self.admm_active)
+                           tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=self.admm_active,
+                           iters=self.admm_iters)
         self._outer_args = capi.OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=0)
         self._outer_args.log = capi._ptr(log)
         self._outer_args.outer_active = capi._ptr(self.outer_active)

@@ -1,0 +1,380 @@
+"""Batched iLQR / DP-form iLQR-ADMM front end with the reference's `iSLS` class surface.
+
+Reference: `iSLS` (isls/isls.py) + `iSLSBase` (isls/isls_base.py).  The public names, arguments and loop
+semantics follow the reference (HEAD names plus the notebook-era aliases listed in SURVEY 8b); every
+numerical step runs in the HIP kernels behind `engine.Engine`:
+
+    backward_pass_DP  -> riccati_gain + riccati_ff           (isls/isls.py:229-308)
+    rollout_DP        -> rollout_ls                          (isls/isls.py:310-334)
+    iterate_once_dp   -> gain, ff, rollout_ls(NaN rule, acceptance test)   (isls/isls.py:336-374)
+    ilqr_admm         -> DP form: ilqr_admm_outer + accept_step            (isls/isls.py:379-501, "TODO: add dp solution")
+
+Differences from the reference, all deliberate and documented in DESIGN.md: `ilqr_admm` uses the DP (Riccati)
+solve instead of the dense batch-form least squares (identical iterates except the never-applied last control,
+SURVEY 8a quirk i); forward models and costs are the built-in device implementations (`isls.models`, via-point
+quadratic cost); status is per trajectory; nothing falls back to the CPU.
+"""
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .admm import ADMM
+from .base import ALPHAS, Base
+from .models import Model
+from .projections import Box
+
+
+class iSLS(Base):
+    def __init__(self, x_dim, u_dim, N, batch=1, dtype=np.float64, device="cuda"):
+        super().__init__(x_dim, u_dim, N, batch=batch, dtype=dtype, device=device)
+        self.alphas = ALPHAS.copy()                             # 10**linspace(0,-5,50), isls/isls_base.py:10-11
+        self._forward_model = None
+        self._cost_function = None
+        self.cost_log = []
+        self._K = self._k = None
+        self._user_AB = False
+
+    # ---- setters / getters (isls/isls_base.py:74-158) ------------------------------------------------------
+    @property
+    def forward_model(self):
+        return self._forward_model
+
+    @forward_model.setter
+    def forward_model(self, model):
+        if not isinstance(model, Model):
+            raise NotImplementedError(
+                "forward_model must be one of isls.models.{LTI, Planar3R, CarSimple}: the rollout runs inside a HIP "
+                "kernel and cannot call back into Python (arbitrary callables are out of scope, SURVEY 7 'hard parts')")
+        if model.x_dim != self.x_dim or model.u_dim != self.u_dim:
+            raise ValueError("model dimensions do not match x_dim/u_dim")
+        self._forward_model = model
+        self.engine.set_model(model.model_id, model.params())
+
+    @property
+    def cost_function(self):
+        return self._cost_function if self._cost_function is not None else self.compute_cost
+
+    @cost_function.setter
+    def cost_function(self, function):
+        if function is not None:
+            raise NotImplementedError("only the via-point quadratic cost (set_cost_variables) has a device "
+                                      "implementation in this round; custom cost callbacks are 'next' (SURVEY 8f-2)")
+        self._cost_function = None
+
+    @property
+    def AB(self):
+        return [self.A, self.B]
+
+    @AB.setter
+    def AB(self, value):
+        """A [N,n,n] / [n,n] (or with a leading batch axis), B likewise: linearisation used by the next backward pass."""
+        A, B = np.asarray(value[0], dtype=np.float64), np.asarray(value[1], dtype=np.float64)
+        self.A, self.B = A, B
+        e = self.engine
+        e.A = e._t(A)
+        e.Bm = e._t(B)
+        self._user_AB = True
+
+    @property
+    def nominal_values(self):
+        return self.x_nom, self.u_nom
+
+    @nominal_values.setter
+    def nominal_values(self, value):
+        self.engine.set_nominal(self._batched(value[0], 2), self._batched(value[1], 2))
+        self.cost_log.append(self.cost)
+
+    @property
+    def x_nom(self):
+        return self._out(self.engine.xhat)
+
+    @property
+    def u_nom(self):
+        return self._out(self.engine.uhat)
+
+    @property
+    def cost(self):
+        c = self.engine.cost.detach().cpu().numpy()
+        return float(c[0]) if self.batch == 1 else c
+
+    @property
+    def K(self):
+        return self._out(self.engine.K)
+
+    @property
+    def k(self):
+        return self._out(self.engine.k)
+
+    @property
+    def status(self):
+        """Per-trajectory status bits (ISLS_ST_*): non-PD Quu, NaN cost, line search rejected."""
+        return self.engine.status.cpu().numpy()
+
+    def reset(self):
+        self.cost_log = []
+        self.engine.status.zero_()
+        self.engine.outer_active.fill_(1)
+
+    def compute_cost(self, x, u=None):
+        """(x-xd)'Q(x-xd) + u'Ru, no 1/2 (SLSBase.compute_cost, isls/sls_base.py:25-44) for arrays [.., N, n]."""
+        x = np.asarray(x, dtype=np.float64)
+        lead = x.shape[:-2]
+        seq = self.seq
+        zs = self.zs if self.zs.ndim == 2 else None
+        if zs is None:
+            raise NotImplementedError("compute_cost on host needs shared via-points; use .cost for per-trajectory targets")
+        dx = x - zs[seq]
+        c = np.einsum("...ti,tij,...tj->...", dx, self.Qs[seq], dx)
+        if u is not None:
+            u = np.asarray(u, dtype=np.float64)
+            c = c + self.u_std * np.sum(u * u, axis=(-1, -2))
+        return float(c) if lead == () else c
+
+    # ---- DP iLQR kernels -----------------------------------------------------------------------------------
+    def _linearize(self, get_AB):
+        e = self.engine
+        model = self._forward_model
+        if get_AB is None or getattr(get_AB, "__self__", None) is model:
+            if model is None:
+                raise ValueError("set forward_model (isls.models.*) or pass get_AB")
+            if self._user_AB:                                   # restore the engine's own dense buffers
+                z = lambda *s: torch.zeros(*s, dtype=e.dtype, device=e.device)   # noqa: E731
+                e.A, e.Bm = z(e.B, e.N, e.n, e.n), z(e.B, e.N, e.n, e.m)
+                self._user_AB = False
+            e.linearize()
+            return
+        # user callback in the reference's convention (numpy, one trajectory): host round trip by design
+        xs, us = e.xhat.cpu().numpy(), e.uhat.cpu().numpy()
+        AB = [get_AB(xs[b], us[b]) for b in range(self.batch)]
+        self.AB = np.stack([np.array(a[0]) for a in AB]), np.stack([np.array(a[1]) for a in AB])
+
+    def _expand(self, Cts=None, cts=None):
+        e = self.engine
+        if Cts is None:
+            e.Cux = None
+            e.expand()
+            return
+        n = self.x_dim
+        Cts, cts = self._batched(Cts, 3), self._batched(cts, 2)
+        e.Cxx.copy_(e._t(Cts[..., :n, :n])), e.Cuu.copy_(e._t(Cts[..., n:, n:]))
+        e.Cux = e._t(Cts[..., n:, :n])
+        e.c0x.copy_(e._t(cts[..., :n])), e.c0u.copy_(e._t(cts[..., n:]))
+
+    def backward_pass_DP(self, Cts=None, cts=None):
+        """Riccati recursion about the nominal (isls/isls.py:229-308).  Returns (K [N,m,n], k [N,m])."""
+        if not self._user_AB:
+            self._linearize(None)                               # built-in model: A_t, B_t along the current nominal
+        self._expand(Cts, cts)
+        self.engine.gain()
+        self.engine.feedforward()
+        return self.K, self.k
+
+    def rollout_DP(self, K, k):
+        """Closed-loop rollout of the candidates k[l] (isls/isls.py:310-334): returns (x_log [L,N,n], u_log [L,N,m])."""
+        e = self.engine
+        k = np.asarray(k, dtype=np.float64)                     # [L,N,m] (batch == 1) or [B,L,N,m]
+        if k.ndim == 3 and self.batch > 1:
+            k = np.broadcast_to(k[None], (self.batch,) + k.shape)
+        Kt = e._t(self._batched(K, 3))
+        xs, us = [], []
+        one = torch.ones(1, dtype=e.dtype, device=e.device)
+        for l in range(k.shape[-3]):
+            kl = e._t(self._batched(k[l] if k.ndim == 3 else k[:, l], 2))
+            e.kern.rollout_ls(e.model, e.model_par, Kt, kl, e.xhat, e.uhat, one, e.Qtab, e.ztab, e.seq, e.u_std, e.xx, e.xu,
+                              q_nonzero=e.q_nonzero, stream=torch.cuda.current_stream().cuda_stream)
+            xs.append(e.xx.cpu().numpy()), us.append(e.xu.cpu().numpy())
+        x, u = np.stack(xs, axis=1), np.stack(us, axis=1)
+        return (x[0], u[0]) if self.batch == 1 else (x, u)
+
+    def iterate_once_dp(self, max_line_search=15, verbose=False, Cts=None, cts=None, _linearized=False):
+        """Backward pass + line search over alphas[:max_line_search] with the NaN rule and the acceptance test
+        (isls/isls.py:336-374).  Returns (fp_success, K, k); fp_success is a bool, or a bool array when batched."""
+        e = self.engine
+        if not _linearized and not self._user_AB:
+            self._linearize(None)
+        self._expand(Cts, cts)
+        e.status.zero_()
+        e.gain(active=e.outer_active)
+        e.feedforward(active=e.outer_active)
+        e.rollout(max_line_search, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST, active=e.outer_active)
+        st = e.status.cpu().numpy()
+        ok = (st & capi.ST_LS_REJECT) == 0
+        if (st & capi.ST_NOT_PD).any():
+            raise np.linalg.LinAlgError(f"Quu not positive definite for trajectories {np.nonzero(st & capi.ST_NOT_PD)[0].tolist()}")
+        e.accept_x_step()                                       # rejected trajectories received their nominal back
+        if self.batch == 1:
+            if ok[0]:
+                self.cost_log.append(self.cost)
+            elif verbose:
+                print("Forward pass failed with a cost of", float(e.cost_new[0]))
+            return bool(ok[0]), self.K, self.k
+        self.cost_log.append(self.cost)
+        return ok, self.K, self.k
+
+    def solve(self, get_AB=None, get_Cs=None, is_dynamics_linear=False, is_cost_quadratic=False, method='dp',
+              max_iter=100, max_line_search_iter=25, tol_fun=1e-5, tol_grad=1e-4, verbose=False):
+        """iLQR outer loop with the reference's stop rules (isls/isls.py:54-132), per trajectory when batched."""
+        if method != 'dp':
+            raise NotImplementedError("only method='dp' is built for MI355X (batch form is O((N m)^3) dense algebra)")
+        e = self.engine
+        e.outer_active.fill_(1)
+        prev = np.atleast_1d(np.array(self.cost, dtype=np.float64)).copy()
+        for i in range(max_iter):
+            if verbose:
+                print("Iteration", i)
+            if not (is_dynamics_linear and i > 0):
+                self._linearize(get_AB)
+            Cts = cts = None
+            if get_Cs is not None:
+                raise NotImplementedError("get_Cs needs a matching device cost for the line search; only the via-point "
+                                          "quadratic cost is built (SURVEY 8f-2)")
+            ok, _, _ = self.iterate_once_dp(max_line_search=max_line_search_iter, verbose=verbose, Cts=Cts, cts=cts,
+                                            _linearized=True)
+            cur = np.atleast_1d(np.array(self.cost, dtype=np.float64))
+            okv = np.atleast_1d(ok)
+            act = e.outer_active.cpu().numpy().astype(bool)
+            # reference: |diff(cost_log[-2:])| < tol_fun (a rejected step leaves cost_log untouched, so the test
+            # is on the last two ACCEPTED costs), then `not fp_success`
+            small = np.abs(cur - prev) < tol_fun
+            stop = act & ((okv & small) | ~okv)
+            prev = np.where(act & okv, cur, prev)
+            act &= ~stop
+            e.outer_active.copy_(torch.as_tensor(act.astype(np.int32), device=e.device))
+            if not act.any():
+                if verbose:
+                    print("Converged / stopped at iteration", i + 1)
+                break
+        return None
+
+    def solve_ilqr(self, get_AB=None, max_ilqr_iter=100, max_line_search_iter=25, dp=True, verbose=False, **kw):
+        """Notebook-era name (Car notebooks :254): iLQR with the quadratic cost set by set_cost_variables."""
+        if not dp:
+            raise NotImplementedError("batch-form iLQR (dp=False) is out of scope; use dp=True")
+        return self.solve(get_AB, method='dp', max_iter=max_ilqr_iter, max_line_search_iter=max_line_search_iter,
+                          verbose=verbose, **kw)
+
+    # ---- iLQR-ADMM (DP form) --------------------------------------------------------------------------------
+    def ilqr_admm(self, get_AB=None, get_Cs=None, project_x=False, project_u=False, max_iter=20,
+                  max_line_search_iter=20, max_admm_iter=20, rho_x=None, rho_u=None, alpha=1, tol=1e-3,
+                  verbose=False, log=False, k_max=None, max_line_search=None, threshold=None):
+        """Outer loop of isls/isls.py:420-499 with the Riccati (DP) inner solve.  Per outer iteration:
+        linearise, expand, then max_admm_iter x [ff pass, line search over alphas[:max_line_search_iter] without
+        acceptance test, z/lambda update] with lambda reset and z warm-started, nominal <- last x-step, and the
+        stop rules |dcost| < 1e-3 / oscillation < 1e-3.  Returns the residual log of the last outer iteration."""
+        if get_Cs is not None:
+            raise NotImplementedError("ilqr_admm with get_Cs needs a device cost for the line search (SURVEY 8f-2)")
+        max_iter = k_max if k_max is not None else max_iter
+        L = max_line_search if max_line_search is not None else max_line_search_iter
+        tol = threshold if threshold is not None else tol
+        e = self.engine
+        px, pu = self._projection(project_x, self.x_dim), self._projection(project_u, self.u_dim)
+        host_proj = (px is not None and not isinstance(px, Box)) or (pu is not None and not isinstance(pu, Box))
+        xb = px.bounds(self.N, self.x_dim) if isinstance(px, Box) else ((-np.inf, np.inf) if px is not None else None)
+        ub = pu.bounds(self.N, self.u_dim) if isinstance(pu, Box) else ((-np.inf, np.inf) if pu is not None else None)
+        zx_keep, zu_keep = e.zx, e.zu
+        e.set_admm(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None,
+                   x_box=xb, u_box=ub, relax=alpha)
+        J = int(max_admm_iter)
+        logbuf = torch.zeros(J, self.batch, 2, dtype=e.dtype, device=e.device)
+        e.outer_active.fill_(1)
+        logs = []
+        for j in range(max_iter):
+            self._linearize(get_AB)
+            e.expand()
+            if host_proj:
+                logs = self._admm_host(px, pu, L, J, tol, alpha, verbose)
+            else:
+                e.build_outer(L, J, tol_abs=tol, tol_rel=tol, log=logbuf)
+                e.run_outer()
+                lb = logbuf.cpu().numpy()
+                logs = [lb[i, 0] if self.batch == 1 else lb[i] for i in range(J)]
+            e.accept_x_step(tol_cost=1e-3, tol_osc=1e-3)
+            self.cost_log.append(self.cost)
+            st = e.status.cpu().numpy()
+            if (st & capi.ST_NOT_PD).any():
+                raise np.linalg.LinAlgError("Quu not positive definite")
+            if verbose:
+                print("Iteration number ", j, "iLQR cost: ", self.cost)
+            if not bool(e.outer_active.any().item()):
+                break
+        # the reference's `logs` holds one [prim, dual] entry per EXECUTED ADMM iteration of the last outer
+        # iteration; batched: all J rows (rows after a trajectory's own stop repeat its last residuals) and
+        # `self.admm_iters` tells how many are real per trajectory
+        self.admm_iters = e.admm_iters.cpu().numpy()
+        return logs[:int(self.admm_iters[0])] if self.batch == 1 and not host_proj else logs
+
+    def _admm_host(self, px, pu, L, J, tol, alpha, verbose):
+        """Generic route for projections without a device kernel: x-step on the GPU, z-step through the caller's
+        numpy functions, one trajectory at a time (isls/admm.py semantics via `isls.admm.ADMM`)."""
+        e = self.engine
+        B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
+        e.gain()
+        res = []
+        # the B trajectories advance in lock-step: every ADMM iteration launches the batched x-step once;
+        # lambda restarts at zero and z is warm-started from the previous outer iteration (isls.py:414-417,489-490)
+        z_x = e.zx.cpu().numpy().reshape(B, -1).copy() if e.zx is not None else None
+        z_u = e.zu.cpu().numpy().reshape(B, -1).copy() if e.zu is not None else None
+        l_x = np.zeros_like(z_x) if z_x is not None else None
+        l_u = np.zeros_like(z_u) if z_u is not None else None
+        prev = np.full((B, 2), 1e6)
+        active = np.ones(B, dtype=bool)
+        for it in range(J):
+            if z_x is not None:
+                e.zx.copy_(e._t(z_x.reshape(B, N, n))), e.lx.copy_(e._t(l_x.reshape(B, N, n)))
+            if z_u is not None:
+                e.zu.copy_(e._t(z_u.reshape(B, N, m))), e.lu.copy_(e._t(l_u.reshape(B, N, m)))
+            act_t = torch.as_tensor(active.astype(np.int32), device=e.device)
+            e.feedforward(active=act_t)
+            e.rollout(L, active=act_t)
+            xx, xu = e.xx.cpu().numpy().reshape(B, -1), e.xu.cpu().numpy().reshape(B, -1)
+            cur = np.zeros((B, 2))
+            for b in range(B):
+                if not active[b]:
+                    cur[b] = prev[b]
+                    continue
+                prim = dual = 0.0
+                for z, l, x, proj in ((z_x, l_x, xx, px), (z_u, l_u, xu, pu)):
+                    if z is None:
+                        continue
+                    fn = proj if not isinstance(proj, Box) else proj.__call__
+                    z_new = np.asarray(fn(alpha * x[b] + (1 - alpha) * z[b] + l[b]), dtype=np.float64).reshape(-1)
+                    r = x[b] - z_new
+                    l[b] += r
+                    prim += np.linalg.norm(r)
+                    dual += np.linalg.norm(z_new - z[b])
+                    z[b] = z_new
+                cur[b] = prim, dual
+                stop = (prim < tol and dual < tol) or (abs(prev[b, 0] - prim) / (prev[b, 0] + 1e-30) < tol and
+                                                       abs(prev[b, 1] - dual) / (prev[b, 1] + 1e-30) < tol)
+                prev[b] = prim, dual
+                if stop:
+                    active[b] = False
+            res.append(cur[0].copy() if B == 1 else cur.copy())
+            if not active.any():
+                break
+        if z_x is not None:
+            e.zx.copy_(e._t(z_x.reshape(B, N, n))), e.lx.copy_(e._t(l_x.reshape(B, N, n)))
+        if z_u is not None:
+            e.zu.copy_(e._t(z_u.reshape(B, N, m))), e.lu.copy_(e._t(l_u.reshape(B, N, m)))
+        return res
+
+    def isls_admm(self, *a, **k):
+        raise NotImplementedError("isls_admm (iterative SLS-ADMM with feedback columns) is the first 'next' row (SURVEY 8f-1)")
+
+    def rollout_batch(self, *a, **k):
+        raise NotImplementedError("batch-form iLQR is out of scope (SURVEY 2, row 10); use the DP form")
+
+    backward_pass_batch = iterate_once_batch = rollout_batch
+
+    # ---- closed-loop evaluation (isls/isls_base.py:62-71) -----------------------------------------------------
+    def get_trajectory_dp(self, x0, K, k, noise_scale=0):
+        """u_t = K_t x_t + k_t, x_{t+1} = f(x_t, u_t) from x0 (absolute form), noise-free only."""
+        if noise_scale:
+            raise NotImplementedError("process noise is drawn on the host in the reference; not built")
+        e = self.engine
+        x0 = self._batched(x0, 1)
+        one = torch.ones(1, dtype=e.dtype, device=e.device)
+        e.kern.rollout_ls(e.model, e.model_par, e._t(self._batched(K, 3)), e._t(self._batched(k, 2)), e.xhat, e.uhat, one,
+                          e.Qtab, e.ztab, e.seq, e.u_std, e.xx, e.xu, x0=e._t(x0), flags=capi.RO_ABSOLUTE,
+                          q_nonzero=e.q_nonzero, stream=torch.cuda.current_stream().cuda_stream)
+        return self._out(e.xx), self._out(e.xu)

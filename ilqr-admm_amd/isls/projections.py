@@ -1,0 +1,276 @@
+"""Projection operators of the ADMM z-step (reference: isls/projections.py).
+
+Two kinds of objects live here:
+
+* `Box` -- a *descriptor* the HIP kernel `admm_update` executes on the device (ISLS_PROJ_BOX); it is also a
+  plain callable on numpy vectors so that it can be passed wherever the reference expects `project_x` /
+  `project_u` callbacks.
+* numpy functions with the reference's names and semantics (`project_bound`, `project_soc_unit`,
+  `project_square_batch`, `project_set_convex`, ...).  They are used by the generic (callback) ADMM path and
+  are pinned against reference outputs in tests/test_projections.py.  Only the box has a device kernel in
+  this round (the others are "next").
+"""
+import numpy as np
+
+
+class Box:
+    """l <= P(x) <= u, element-wise (np.clip; isls/projections.py:7-11).  lo/hi: scalars, [d], [N,d] or flat [N*d]."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = lo, hi
+
+    def __call__(self, x):
+        return np.clip(x, np.broadcast_to(np.asarray(self.lo).reshape(-1), np.shape(x)) if np.ndim(self.lo) > 1 else self.lo,
+                       np.broadcast_to(np.asarray(self.hi).reshape(-1), np.shape(x)) if np.ndim(self.hi) > 1 else self.hi)
+
+    def bounds(self, N, d):
+        """(lo, hi) as float64 arrays broadcastable to [N, d]."""
+        def expand(v):
+            v = np.asarray(v, dtype=np.float64)
+            if v.ndim == 0:
+                return np.full((1, d), float(v))
+            if v.size == N * d:
+                return v.reshape(N, d)
+            return v.reshape(1, d)
+        return expand(self.lo), expand(self.hi)
+
+
+def identify_box(project, size, rng_seed=0):
+    """Recognise an opaque `project(flat_vector)` callback as a box and return the equivalent `Box`, else None.
+
+    The reference's notebooks pass lambdas such as `lambda u: project_bound(u, -5, 5)`.  A map P is the
+    projection on a box iff P(v) = clip(v, lo, hi) with lo = P(-inf..), hi = P(+inf..); we read lo/hi off two
+    extreme probes and verify the identity on random vectors (exact comparison).
+    """
+    big = 1e300
+    try:
+        hi = np.asarray(project(np.full(size, big)), dtype=np.float64).reshape(-1)
+        lo = np.asarray(project(np.full(size, -big)), dtype=np.float64).reshape(-1)
+    except Exception:
+        return None
+    if hi.shape != (size,) or lo.shape != (size,) or np.any(lo > hi):
+        return None
+    hi = np.where(hi >= big, np.inf, hi)
+    lo = np.where(lo <= -big, -np.inf, lo)
+    rng = np.random.default_rng(rng_seed)
+    fin = np.isfinite(lo) | np.isfinite(hi)
+    scale = 1.0 + (np.max(np.abs(np.concatenate([lo[np.isfinite(lo)], hi[np.isfinite(hi)]]))) if fin.any() else 0.0)
+    for _ in range(4):
+        v = rng.standard_normal(size) * 3.0 * scale
+        try:
+            out = np.asarray(project(v.copy()), dtype=np.float64).reshape(-1)
+        except Exception:
+            return None
+        if out.shape != (size,) or not np.array_equal(out, np.clip(v, lo, hi)):
+            return None
+    return Box(lo, hi)
+
+
+# ---- primitives ------------------------------------------------------------------------------------
+def project_bound(x, l, u):
+    """l <= P(x) <= u  (isls/projections.py:7-11)."""
+    return np.clip(x, l, u)
+
+
+def project_linear_batch(x, a, l, u):
+    """Rows x_i onto the slab l <= a_i'x_i <= u  (isls/projections.py:30-43)."""
+    ax = np.einsum("ij,ij->i", x, a)
+    aa = np.einsum("ij,ij->i", a, a) + 1e-30
+    excess = np.where(ax > u, ax - u, np.where(ax < l, ax - l, 0.0))
+    return x - (excess / aa)[:, None] * a
+
+
+def project_linear(x, a, l, u):
+    """x onto l <= a'x <= u  (isls/projections.py:13-28)."""
+    if x.ndim == 2:
+        return project_linear_batch(x, a, l, u)
+    ax, aa = a.dot(x), a.dot(a) + 1e-30
+    mu = ax - u if ax > u else (ax - l if ax < l else 0.0)
+    return x - mu * a / aa
+
+
+def project_affine(x, a, b, l, u):
+    """l <= a'x + b <= u  (isls/projections.py:64-68)."""
+    return project_linear(x, a, l - b, u - b)
+
+
+def project_multilinear(x, A, l, u):
+    """Boundary projection for l <= A x <= u (not the minimum-norm one; isls/projections.py:46-61)."""
+    Ax = A.dot(x)
+    target = np.where(Ax > u, u, np.where(Ax < l, l, Ax))
+    return x - A.T @ (np.linalg.inv(A @ A.T) @ (Ax - target))
+
+
+def project_quadratic_batch(x, l, u):
+    """Rows onto the shell l <= 0.5 |x|^2 <= u  (isls/projections.py:91-105)."""
+    val = 0.5 * np.sum(x * x, axis=-1)
+    nrm = np.linalg.norm(x, axis=-1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out_hi = x * (np.sqrt(2 * u) / nrm)[:, None]
+        out_lo = x * (np.sqrt(2 * l) / nrm)[:, None]
+    z = np.where((val > u)[:, None], out_hi, x)
+    return np.where((l > val)[:, None], out_lo, z)
+
+
+def project_quadratic(x, l, u):
+    if x.ndim == 2:
+        return project_quadratic_batch(x, l, u)
+    raise NotImplementedError                                  # as in the reference (isls/projections.py:77)
+
+
+def project_quadratic_b(x, b, l, u):
+    """l <= 0.5 x'x + b'x <= u  (isls/projections.py:107-115)."""
+    const = 0.5 * b.T.dot(b)
+    return project_quadratic(x + b, l + const, u + const) - b
+
+
+def project_soc_unit_batch(z, t):
+    """Rows (z_i, t_i) onto the second-order cone |z| <= t.  Mask precedence follows the reference
+    (isls/projections.py:140-162): boundary formula, then the polar-cone zeroing, then the interior identity."""
+    nz = np.linalg.norm(z, axis=-1)
+    half = (nz + t) / 2
+    inside = nz <= t
+    polar = (nz <= -t) | (t < 0)
+    z_out = np.where(inside[:, None], z, np.where(polar[:, None], 0.0, half[:, None] * z / (nz[:, None] + 1e-30)))
+    t_out = np.where(inside, t, np.where(polar, 0.0, half))
+    return z_out, t_out
+
+
+def project_soc_unit(zt):
+    """[z, t] onto |z| <= t; accepts a vector or rows  (isls/projections.py:118-137)."""
+    z, t = zt[..., :-1], zt[..., -1]
+    if z.ndim == 2:
+        z_, t_ = project_soc_unit_batch(z, t)
+        return np.concatenate([z_, t_[:, None]], axis=1)
+    nz = np.linalg.norm(z)
+    if nz <= t:
+        return np.append(z, t)
+    if nz <= -t:
+        return np.append(z * 0, t * 0)
+    half = (nz + t) / 2
+    return np.append(half * z / (nz + 1e-30), half)
+
+
+def project_unit_ball(x):
+    n = np.linalg.norm(x)
+    return x if n <= 1 else x / n
+
+
+def project_square_batch(x, l, u):
+    """Rows onto l <= |x|_inf <= u  (isls/projections.py:256-266): the dominant coordinate is pushed out to l."""
+    z = np.array(x, dtype=float, copy=True)
+    j = np.argmax(np.abs(x), axis=-1)
+    rows = np.nonzero(np.abs(x).max(axis=-1) < l)[0]
+    z[rows, j[rows]] = l * np.sign(x[rows, j[rows]])
+    return np.clip(z, -u, u)
+
+
+def project_square(x, l, u):
+    """Vector version (isls/projections.py:245-254)."""
+    z = np.array(x, dtype=float, copy=True)
+    j = int(np.argmax(np.abs(x)))
+    if abs(x[j]) < l:
+        z[j] = l * np.sign(x[j])
+    return np.clip(z, -u, u)
+
+
+def project_square_c(x, c, l, u):
+    return project_square(x - c, l, u) + c
+
+
+def project_block_lower_triangular(z, x_dim, u_dim, N):
+    """isls/projections.py:277-282."""
+    for i in range(N):
+        z[i * u_dim, i * x_dim:(i + 1) * x_dim] = 0.0
+    return z
+
+
+projections = {"SOC": project_soc_unit, "bound": project_bound, "linear": project_linear,
+               "quadratic": project_quadratic, "square": project_square}
+
+
+def _consensus_residual_loop(update, max_iter, threshold, rel=1e-5):
+    """Shared stop logic of the reference's inner ADMM solvers: max-norm residuals below `threshold`, or both
+    relative changes below 1e-5 (isls/projections.py:349-372)."""
+    prev_p, prev_d = 1e5, 1e5
+    for j in range(max_iter):
+        p, d = update()
+        if p < threshold and d < threshold:
+            break
+        if j < max_iter - 1:
+            if abs(prev_p - p) / (prev_p + 1e-30) < rel and abs(prev_d - d) / (prev_d + 1e-30) < rel:
+                break
+        prev_p, prev_d = p, d
+
+
+def project_set_convex(x0, As=[], bs=[], projections=[], rho=1, max_iter=200, threshold=1e-4, verbose=False):
+    """Projection onto the intersection {x : A_i x + b_i in C_i} by consensus ADMM (isls/projections.py:289-374):
+    x = (I + rho sum A_i'A_i)^-1 (x0 + rho sum A_i'(z_i - b_i - lmb_i)); z_i = P_i(A_i x + b_i + lmb_i); lmb_i += A_i x + b_i - z_i."""
+    single = x0.ndim == 1
+    X0 = (x0[None] if single else x0).T
+    x = X0.copy()
+    z = [A @ x + b[:, None] for A, b in zip(As, bs)]
+    lmb = [np.zeros_like(zi) for zi in z]
+    lhs_inv = np.linalg.inv(np.eye(X0.shape[0]) + rho * sum(A.T @ A for A in As))
+    state = {"x": x}
+
+    def update():
+        rhs = sum(A.T @ (zi - b[:, None] - li) for A, b, zi, li in zip(As, bs, z, lmb))
+        xk = lhs_inv @ (X0 + rho * rhs)
+        p_max = d_max = 0.0
+        for i, (A, b, P) in enumerate(zip(As, bs, projections)):
+            Axb = A @ xk + b[:, None]
+            z_new = P((Axb + lmb[i]).T).T
+            prim = Axb - z_new
+            dual = rho * A.T @ (z_new - z[i])
+            lmb[i] = lmb[i] + prim
+            z[i] = z_new
+            p_max = max(p_max, float(np.max(np.linalg.norm(prim, axis=0))))
+            d_max = max(d_max, float(np.max(np.linalg.norm(dual, axis=0))))
+        state["x"] = xk
+        return p_max, d_max
+
+    _consensus_residual_loop(update, max_iter, threshold)
+    out = state["x"].T
+    return out[0] if single else out
+
+
+def project_soc(z0, A, b, rho=1e0, max_iter=100, tol=1e-5, verbose=False):
+    """Projection onto {z : A z + b in SOC} by ADMM (isls/projections.py:163-234)."""
+    single = z0.ndim == 1
+    Z0 = (z0[None] if single else z0).T
+    z = Z0.copy()
+    lmb = np.zeros((A.shape[0], Z0.shape[1]))
+    lhs_inv = np.linalg.inv(np.eye(Z0.shape[0]) + rho * A.T @ A)
+    state = {"z": z}
+
+    def update():
+        zk = state["z"]
+        x = project_soc_unit((A @ zk + b[:, None] + lmb).T).T
+        z_new = lhs_inv @ (Z0 + rho * A.T @ (-b[:, None] + x - lmb))
+        prim = A @ z_new + b[:, None] - x
+        dual = rho * (z_new - zk)
+        lmb[...] = lmb + prim
+        state["z"] = z_new
+        return float(np.max(np.linalg.norm(prim, axis=0))), float(np.max(np.linalg.norm(dual, axis=0)))
+
+    _consensus_residual_loop(update, max_iter, tol)
+    out = state["z"].T
+    return out[0] if single else out
+
+
+def project_set_convex_dykstra(x0, projections=[], max_iter=200, tol=1e-4, verbose=False):
+    """Dykstra's alternating projections (isls/projections.py:465-504)."""
+    single = x0.ndim == 1
+    u = (x0[None] if single else x0).copy()
+    z = np.zeros((len(projections),) + u.shape)
+    k, cI = 0, np.full(u.shape[0], 10.0)
+    while k <= max_iter and np.any(cI >= tol):
+        cI = np.zeros(u.shape[0])
+        for i, P in enumerate(projections):
+            prev_u, prev_z = u, z[i].copy()
+            u = P(prev_u - prev_z)
+            z[i] = u - (prev_u - prev_z)
+            cI += np.linalg.norm(prev_z - z[i], axis=-1) ** 2
+        k += 1
+    return u

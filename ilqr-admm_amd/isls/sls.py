@@ -1,0 +1,196 @@
+"""Batched LQT / LQT-ADMM (DP form) front end with the reference's `SLS` class surface.
+
+Reference: `SLS` (isls/sls.py) + `SLSBase` (isls/sls_base.py).  Built on the same HIP kernels as `iSLS`, in
+their absolute-coordinate / explicit-inverse mode (`ISLS_SOLVE_INV`, `ISLS_RO_ABSOLUTE`):
+
+    solve_dp(Qr,Rr,ur,xr,return_Qs) -> expand_quadratic + riccati_gain(INV) + riccati_ff   (isls/sls.py:85-166)
+    solve_dp_ff                     -> riccati_ff with the cached K, Quu, Quu_inv, Qux       (isls/sls.py:168-202)
+    get_trajectory_dp               -> rollout_ls(ABSOLUTE)                                  (isls/sls_base.py:76-89)
+    ADMM_LQT_DP                     -> gain once, then per iteration ff + rollout + admm_update (isls/sls.py:298-317)
+
+The batch-form / SLS (dense (N m)^2) solvers -- solve_batch, solve_sls, ADMM_LQT_Batch, ADMM_SLS, controller --
+are config 5 of BASELINE.json and not part of this round's hot path: they raise NotImplementedError.
+"""
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .base import Base
+from .models import LTI
+from .projections import Box
+
+
+class SLS(Base):
+    def __init__(self, x_dim, u_dim, N, batch=1, dtype=np.float64, device="cuda"):
+        super().__init__(x_dim, u_dim, N, batch=batch, dtype=dtype, device=device)
+        self.engine.solve_mode = capi.SOLVE_INV
+        self._model = None
+
+    # ---- dynamics -------------------------------------------------------------------------------------------
+    @property
+    def AB(self):
+        return [self.A, self.B]
+
+    @AB.setter
+    def AB(self, value):
+        """LTI dynamics A [n,n], B [n,m] (isls/base.py:98-119; the Sw/Su transfer matrices of the batch form are
+        not built: the DP form never needs them)."""
+        self.A, self.B = np.asarray(value[0], dtype=np.float64), np.asarray(value[1], dtype=np.float64)
+        if self.A.ndim != 2:
+            raise NotImplementedError("SLS is the LTI class of the reference (sls.py:139-140); use iSLS for time-varying A,B")
+        self._model = LTI(self.A, self.B)
+        e = self.engine
+        e.set_model(self._model.model_id, self._model.params())
+        e.A, e.Bm = e._t(self.A).reshape(1, 1, self.x_dim, self.x_dim), e._t(self.B).reshape(1, 1, self.x_dim, self.u_dim)
+
+    def forward_model(self, x, u):
+        return self._model(np.asarray(x), np.asarray(u))
+
+    def compute_cost(self, x, u=None, cost_function=None):
+        """(x-xd)'Q(x-xd) + u'Ru without the 1/2 (isls/sls_base.py:25-44); x [N,n] / flat, or with leading batch axes."""
+        if cost_function is not None:
+            return cost_function(x=x, u=u)
+        x = np.asarray(x, dtype=np.float64)
+        x = x.reshape(x.shape[:-1] + (self.N, self.x_dim)) if x.shape[-1] == self.N * self.x_dim else x
+        dx = x - self.zs[self.seq]
+        c = np.einsum("...ti,tij,...tj->...", dx, self.Qs[self.seq], dx)
+        if u is not None:
+            u = np.asarray(u, dtype=np.float64)
+            c = c + self.u_std * np.sum(u * u, axis=tuple(range(x.ndim - 2, u.ndim)))
+        return float(c) if np.ndim(c) == 0 else c
+
+    # ---- DP solvers -----------------------------------------------------------------------------------------
+    def _set_reg(self, Qr, Rr, xr, ur):
+        """Regulariser of the ADMM sub-problem (isls/sls.py:104-137): weights Qr [N,n,n] / Rr list, targets xr, ur."""
+        e = self.engine
+        B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
+        z = lambda *s: torch.zeros(*s, dtype=e.dtype, device=e.device)   # noqa: E731
+        e.Qr = None if Qr is None else e._t(np.asarray(Qr))
+        e.Rr = None if Rr is None else e._t(np.stack([np.asarray(r) for r in Rr]) if isinstance(Rr, (list, tuple)) else np.asarray(Rr))
+        if Qr is not None:
+            assert xr is not None
+            e.zx, e.lx = e._t(self._batched(np.asarray(xr).reshape(-1, N, n) if np.ndim(xr) > 1 else np.asarray(xr).reshape(N, n), 2)), z(B, N, n)
+        else:
+            e.zx = e.lx = None
+        if Rr is not None:
+            assert ur is not None
+            e.zu, e.lu = e._t(self._batched(np.asarray(ur).reshape(-1, N, m) if np.ndim(ur) > 1 else np.asarray(ur).reshape(N, m), 2)), z(B, N, m)
+        else:
+            e.zu = e.lu = None
+
+    def _expand_abs(self):
+        e = self.engine
+        e.kern.expand_quadratic(e.Qtab, e.ztab, e.seq, e.u_std, e.c0x, e.c0u, Cxx=e.Cxx, Cuu=e.Cuu, Qr=e.Qr, Rr=e.Rr,
+                                stream=torch.cuda.current_stream().cuda_stream)
+
+    def _ff_abs(self):
+        e = self.engine
+        e.kern.riccati_ff(e.A, e.Bm, e.c0x, e.c0u, e.K, e.Quu, e.fac, e.Qux, e.k, Qr=e.Qr, Rr=e.Rr, zx=e.zx, lx=e.lx,
+                          zu=e.zu, lu=e.lu, solve_mode=capi.SOLVE_INV, stream=torch.cuda.current_stream().cuda_stream)
+
+    def solve_dp(self, Qr=None, Rr=None, ur=None, xr=None, return_Qs=False):
+        assert self.A is not None, "Set the linear dynamics model by self.AB = [A,B] before calling this method."
+        assert self.Q is not None, "Set the quadratic cost model by self.set_cost_variables() before calling this method."
+        e = self.engine
+        self._set_reg(Qr, Rr, xr, ur)
+        self._expand_abs()
+        e.status.zero_()
+        e.gain()
+        self._ff_abs()
+        if (e.status.cpu().numpy() & capi.ST_NOT_PD).any():
+            raise np.linalg.LinAlgError("Singular matrix")
+        if return_Qs:
+            return self._out(e.K), self._out(e.k), self._out(e.Quu), self._out(e.fac), self._out(e.Qux)
+        return self._out(e.K), self._out(e.k)
+
+    def solve_dp_ff(self, K, Quu, Qux, Quu_inv, Qr=None, Rr=None, ur=None, xr=None):
+        e = self.engine
+        e.K.copy_(e._t(self._batched(K, 3))), e.Quu.copy_(e._t(self._batched(Quu, 3)))
+        e.Qux.copy_(e._t(self._batched(Qux, 3))), e.fac.copy_(e._t(self._batched(Quu_inv, 3)))
+        self._set_reg(Qr, Rr, xr, ur)
+        self._expand_abs()
+        self._ff_abs()
+        return self._out(e.k)
+
+    def solve(self, x0=None, method='sls'):
+        if method == 'dp':
+            return self.solve_dp()
+        raise NotImplementedError("only method='dp' is built (batch / sls forms: config 5, later round)")
+
+    def get_trajectory_dp(self, x0, K, k, noise_scale=0):
+        """u_t = K_t x_t + k_t, x_{t+1} = A x_t + B u_t  (isls/sls_base.py:76-89).  x0 [n] -> one trajectory per problem
+        of the batch; x0 [M,n] with batch == 1 evaluates M initial states against the same controller (Monte Carlo)."""
+        if noise_scale:
+            raise NotImplementedError("process noise is drawn on the host in the reference; not built")
+        x0 = np.asarray(x0, dtype=np.float64)
+        e = self.engine
+        if x0.ndim == 2 and self.batch == 1 and x0.shape[0] != 1:
+            M = x0.shape[0]
+            mc = SLS(self.x_dim, self.u_dim, self.N, batch=M, dtype=self.np_dtype, device=e.device)
+            mc.AB = [self.A, self.B]
+            mc.set_quadratic_cost(self.zs, self.Qs, self.seq, self.u_std)
+            return mc.get_trajectory_dp(x0, K, k)
+        x0 = self._batched(x0, 1)
+        one = torch.ones(1, dtype=e.dtype, device=e.device)
+        e.kern.rollout_ls(e.model, e.model_par, e._t(self._batched(K, 3)), e._t(self._batched(k, 2)), e.xhat, e.uhat, one,
+                          e.Qtab, e.ztab, e.seq, e.u_std, e.xx, e.xu, x0=e._t(x0), flags=capi.RO_ABSOLUTE,
+                          q_nonzero=e.q_nonzero, stream=torch.cuda.current_stream().cuda_stream)
+        return self._out(e.xx), self._out(e.xu)
+
+    # ---- LQT-ADMM, DP form --------------------------------------------------------------------------------------
+    def ADMM_LQT_DP(self, x0, project_x=False, project_u=False, max_iter=2000, rho_x=None, rho_u=None, alpha=1.,
+                    tol=1e-3, verbose=False, log=False):
+        """isls/sls.py:298-317: gain pass once, then ADMM iterations of [ff pass, closed-loop rollout from x0,
+        z/lambda update] with the stop rules of isls/admm.py:72-85.  Returns (x_flat, u_flat, K, k[, logs])."""
+        e = self.engine
+        B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
+        px, pu = self._projection(project_x, n), self._projection(project_u, m)
+        for p_ in (px, pu):
+            if p_ is not None and not isinstance(p_, Box):
+                raise NotImplementedError("ADMM_LQT_DP on the device needs box constraints (projections.Box or a callable "
+                                          "that is recognisably a box); other sets are 'next' (SURVEY 8f-4)")
+        Qr, Rr = self.compute_Rr_Qr(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None, dp=True)
+        self.solve_dp(Rr=Rr, Qr=Qr, xr=np.zeros(N * n), ur=np.zeros(N * m))
+        if px is not None:
+            e.x_lo, e.x_hi = (e._t(v) for v in px.bounds(N, n))
+        if pu is not None:
+            e.u_lo, e.u_hi = (e._t(v) for v in pu.bounds(N, m))
+        x0t = e._t(self._batched(x0, 1))
+        one = torch.ones(1, dtype=e.dtype, device=e.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        e.res_prev.fill_(1e6)
+        e.admm_active.fill_(1)
+        e.admm_iters.zero_()
+        logs, chunk = [], 16
+        for j0 in range(0, max_iter, chunk):                    # host looks at the stop flags every `chunk` iterations
+            nrun = min(chunk, max_iter - j0)
+            buf = torch.zeros(nrun, B, 2, dtype=e.dtype, device=e.device)
+            iters_before = e.admm_iters.clone()
+            for j in range(nrun):
+                e.kern.riccati_ff(e.A, e.Bm, e.c0x, e.c0u, e.K, e.Quu, e.fac, e.Qux, e.k, Qr=e.Qr, Rr=e.Rr, zx=e.zx,
+                                  lx=e.lx, zu=e.zu, lu=e.lu, solve_mode=capi.SOLVE_INV, active=e.admm_active, stream=stream)
+                e.kern.rollout_ls(e.model, e.model_par, e.K, e.k, e.xhat, e.uhat, one, e.Qtab, e.ztab, e.seq, e.u_std,
+                                  e.xx, e.xu, x0=x0t, flags=capi.RO_ABSOLUTE, q_nonzero=e.q_nonzero,
+                                  active=e.admm_active, stream=stream)
+                e.kern.admm_update(e.xx, e.xu, e.res, zx=e.zx, lx=e.lx, zu=e.zu, lu=e.lu,
+                                   x_lo=e.x_lo if px is not None else None, x_hi=e.x_hi if px is not None else None,
+                                   u_lo=e.u_lo if pu is not None else None, u_hi=e.u_hi if pu is not None else None,
+                                   relax=alpha, tol_abs=tol, tol_rel=tol, res_prev=e.res_prev, active=e.admm_active,
+                                   iters=e.admm_iters, stream=stream)
+                buf[j].copy_(e.res)
+            done = (e.admm_iters - iters_before).cpu().numpy()
+            bh = buf.cpu().numpy()
+            for j in range(int(done.max())):
+                logs.append(bh[j, 0] if B == 1 else bh[j])
+            if not bool(e.admm_active.any().item()):
+                break
+        out = (self._out(e.xx).reshape(-1) if B == 1 else e.xx.cpu().numpy().reshape(B, -1),
+               self._out(e.xu).reshape(-1) if B == 1 else e.xu.cpu().numpy().reshape(B, -1), self._out(e.K), self._out(e.k))
+        return out + ((logs,) if log else ())
+
+    # ---- out of scope this round (config 5 / dense batch form) -----------------------------------------------------
+    def _config5(self, *a, **k):
+        raise NotImplementedError("dense batch-form / SLS solvers (config 5 of BASELINE.json) are not built in this round")
+
+    solve_batch = solve_sls = controller = ADMM_LQT_Batch = ADMM_SLS = _config5
+    initialize_replanning_procedure = replan_feedforward = get_trajectory_sls = get_trajectory_batch = _config5

@@ -178,7 +178,8 @@ int isls_rollout_ls_f32(const isls_rollout_args *a, void *stream);
  *   prim = |r_x| + |r_u| ; dual = |z_x - z_prev_x| + |z_u - z_prev_u|        (unscaled 2-norms)
  *   stop  if prim<tol_abs and dual<tol_abs, else if both relative changes (vs res_prev, +1e-30) < tol_rel
  * res[B,2] receives (prim,dual); res_prev[B,2] is read then overwritten with them (init 1e6, admm.py:25-26);
- * active[b] is cleared when a stop rule fires (nullable => no stop rule evaluated).
+ * active[b] is cleared when a stop rule fires (nullable => no stop rule evaluated); iters[b] counts the
+ * executed ADMM iterations of trajectory b (the length of the reference's `logs`, admm.py:71).
  * ------------------------------------------------------------------------------------------- */
 typedef struct isls_admm_args {
     int32_t B, N, n, m;
@@ -190,6 +191,7 @@ typedef struct isls_admm_args {
     isls_view u_lo, u_hi;      /* [.,.,m] */
     void *res, *res_prev;
     int32_t *active;
+    int32_t *iters;            /* [B] nullable: incremented for every trajectory updated by this call */
 } isls_admm_args;
 
 int isls_admm_update_f64(const isls_admm_args *a, void *stream);

@@ -467,6 +467,7 @@ int FN(oracle_admm_update)(const isls_admm_args *a)
         }
         res[0] = prim; res[1] = dual;
         if (prev) { prev[0] = prim; prev[1] = dual; }
+        if (a->iters) a->iters[b] += 1;
     }
     return ISLS_OK;
 }
@@ -633,6 +634,7 @@ int FN(oracle_ilqr_admm_outer)(const isls_outer_args *a)
         const int act = a->outer_active ? (a->outer_active[b] != 0) : 1;
         if (a->admm.active) a->admm.active[b] = act;
         if (!act) continue;
+        if (a->admm.iters) a->admm.iters[b] = 0;
         if (a->admm.lx) for (int e = 0; e < N * n; ++e) ((REAL *)a->admm.lx)[(int64_t)b * N * n + e] = 0;
         if (a->admm.lu) for (int e = 0; e < N * m; ++e) ((REAL *)a->admm.lu)[(int64_t)b * N * m + e] = 0;
         if (a->admm.res_prev) { ((REAL *)a->admm.res_prev)[2 * b] = (REAL)1e6; ((REAL *)a->admm.res_prev)[2 * b + 1] = (REAL)1e6; }
