@@ -79,6 +79,7 @@ def main():
     import isls_problems as P
     from isls import _capi as capi
     from isls.engine import Engine, library
+    from isls.shard import allreduce_convergence
 
     B, N, J, L = args.batch, args.horizon, args.J, args.L
     cfg = P.config2(batch=B, N=N, seed=rank)
@@ -104,12 +105,7 @@ def main():
         eng.run_outer()                                       # gain + J x (ff, rollout, update), one C call
         eng.accept_x_step()                                   # nominal <- x-step, cost log (no stop rule)
         eng.reduce()
-        if dist is not None:
-            red.zero_()
-            red[rank].copy_(eng.out5)
-            dist.all_reduce(red)                              # the one collective: 5 doubles per rank
-        else:
-            red[0].copy_(eng.out5)
+        allreduce_convergence(eng.out5, rank, world, buf=red)  # the one collective: 5 doubles per rank (RCCL)
 
     lib = library()
     for _ in range(args.warmup):

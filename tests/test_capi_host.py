@@ -1,0 +1,139 @@
+"""CPU-side checks of the boundary: the HIP library loads and exports every entry point include/isls_hip.h
+declares (no compute call -- there is no GPU here), the ctypes structs mirror the header, the strided-view
+marshaling and the sharding / reduction logic (world_size 2 over gloo)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from isls import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "isls_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(isls_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load_hip_library()
+    names = header_functions()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTED) == names                      # the binding knows exactly the header's surface
+    lib.isls_version.restype = ctypes.c_int
+    assert lib.isls_version() == 100
+    assert b"unsupported" in lib.isls_error_string(capi.ERR_UNSUPPORTED)
+
+
+def test_struct_layouts_match_header():
+    """sizeof of every argument struct as compiled from the header by gcc == ctypes' layout."""
+    import subprocess
+    import tempfile
+    names = ["gain", "ff", "rollout", "admm", "expand", "linearize", "accept", "outer"]
+    src = '#include <stdio.h>\n#include "isls_hip.h"\nint main(){' + "".join(
+        f'printf("%zu\\n", sizeof(isls_{n}_args));' for n in names) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "s"), os.path.join(d, "s.c")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    structs = [capi.GainArgs, capi.FfArgs, capi.RolloutArgs, capi.AdmmArgs, capi.ExpandArgs, capi.LinearizeArgs,
+               capi.AcceptArgs, capi.OuterArgs]
+    assert sizes == [ctypes.sizeof(s) for s in structs]
+
+
+def test_make_view_strides():
+    B, N, n = 5, 7, 3
+    dense = np.zeros((B, N, n, n))
+    v = capi.make_view(dense, B, N, (n, n), "A")
+    assert (v.sb, v.st) == (N * n * n, n * n)
+    v = capi.make_view(np.zeros((n, n)), B, N, (n, n), "A")
+    assert (v.sb, v.st) == (0, 0)
+    v = capi.make_view(np.zeros((N, n, n)), B, N, (n, n), "A")
+    assert (v.sb, v.st) == (0, n * n)
+    v = capi.make_view(np.zeros((B, 1, n, n)), B, N, (n, n), "A")          # per-trajectory LTI
+    assert (v.sb, v.st) == (n * n, 0)
+    v = capi.make_view(np.broadcast_to(np.zeros((1, 1, n, n)), (B, N, n, n)), B, N, (n, n), "A")
+    assert (v.sb, v.st) == (0, 0)
+    assert capi.make_view(None, B, N, (n,), "x").p is None
+    with pytest.raises(ValueError):
+        capi.make_view(np.zeros((B, N, n, n + 1)), B, N, (n, n), "A")
+    with pytest.raises(ValueError):
+        capi.make_view(np.zeros((B, N, n, n)).transpose(0, 1, 3, 2), B, N, (n, n), "A")
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host side before anything touches a device."""
+    lib = capi.load_hip_library()
+    a = capi.GainArgs(B=4, N=10, n=6, m=3)
+    lib.isls_riccati_gain_f64.restype = ctypes.c_int
+    assert lib.isls_riccati_gain_f64(ctypes.byref(a), None) == capi.ERR_ARG            # null pointers
+    assert lib.isls_riccati_gain_f64(None, None) == capi.ERR_ARG
+    r = capi.RolloutArgs(B=1, N=10, n=6, m=3, L=65)
+    lib.isls_rollout_ls_f64.restype = ctypes.c_int
+    assert lib.isls_rollout_ls_f64(ctypes.byref(r), None) == capi.ERR_ARG               # L > 64
+    k = capi.Kernels(lib)
+    with pytest.raises(ValueError):
+        k.gain_args(np.zeros((2, 2)), np.zeros((2, 1)), np.zeros((2, 2)), np.zeros((1, 1)), np.zeros((3, 5, 1, 2)),
+                    np.zeros((3, 5, 1, 1)), np.zeros((3, 5, 1, 1)), np.zeros((3, 5, 2, 2)))   # Qux has the wrong shape
+
+
+def test_shard_range():
+    from isls.shard import shard_range
+    for B, W in ((4096, 8), (10, 3), (7, 8)):
+        cuts = [shard_range(B, r, W) for r in range(W)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == B
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+        assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1
+
+
+def _rank_main(rank, world, port, B, ret):
+    import torch
+    import torch.distributed as dist
+
+    import isls_problems as P
+    from helpers import OracleDriver, problem_arrays
+    from isls.shard import allreduce_convergence, shard_range
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kern, _ = orc.load()
+    cfg = P.config2(batch=B, N=30, seed=0)
+    lo, hi = shard_range(B, rank, world)
+    d = OracleDriver(kern, problem_arrays(cfg, range(lo, hi)), rho_u=cfg["rho_u"])
+    d.run_c(8, 2)
+    out5 = np.zeros(5)
+    kern.reduce_convergence(d.cost, d.res, d.outer_active, d.status, out5)
+    total, table = allreduce_convergence(torch.from_numpy(out5), rank, world)
+    ret[rank] = (total.numpy().copy(), table.numpy().copy(), d.xhat.copy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(oracle):
+    """The N>1 path: two gloo ranks, each solving its shard with the same kernels' CPU oracle, exchange only the
+    [W,5] convergence table; trajectories and the reduced summary equal the single-process run."""
+    import torch.multiprocessing as mp
+
+    import isls_problems as P
+    from helpers import OracleDriver, problem_arrays
+    B, world = 9, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank_main, args=(world, 29517, B, ret), nprocs=world, join=True)
+    cfg = P.config2(batch=B, N=30, seed=0)
+    d = OracleDriver(oracle, problem_arrays(cfg, range(B)), rho_u=cfg["rho_u"])
+    d.run_c(8, 2)
+    full = np.zeros(5)
+    oracle.reduce_convergence(d.cost, d.res, d.outer_active, d.status, full)
+    x = np.concatenate([ret[r][2] for r in range(world)])
+    assert np.array_equal(x, d.xhat)
+    for r in range(world):
+        total, table = ret[r][0], ret[r][1]
+        assert table.shape == (world, 5)
+        assert abs(total[0] - full[0]) < 1e-9 * max(1.0, abs(full[0]))
+        assert np.allclose(total[1:], full[1:], rtol=1e-15, atol=0)
