@@ -85,8 +85,9 @@ def main():
     cfg = P.config2(batch=B, N=N, seed=rank)
     n, m = cfg["n"], cfg["m"]
     eng = Engine(B, N, n, m, dtype=torch.float64, device=dev)
-    par = np.concatenate([cfg["A"].ravel(), cfg["B"].ravel()])
-    eng.set_model(capi.MODEL_LTI, par)
+    from isls import models
+    mdl = models.LTI(cfg["A"], cfg["B"])      # recognised as a double integrator -> ISLS_MODEL_DI (same numbers as the dense LTI map)
+    eng.set_model(mdl.model_id, mdl.params())
     eng.set_quadratic_cost(cfg["zs"], cfg["Qs"], cfg["seq"], cfg["u_std"])
     # initial nominal: u = 0 from x0 (the double integrator keeps position, zero velocity)
     x_nom = np.repeat(cfg["x0"][:, None, :], N, axis=1)

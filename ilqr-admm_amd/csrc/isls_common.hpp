@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/isls_hip.h"
 
@@ -157,6 +158,16 @@ template <typename T> int launch_reduce(int32_t B, const void *cost, const void 
 template <typename T> int launch_outer_begin(int32_t B, int32_t N, int32_t n, int32_t m, int32_t *admm_active,
                                              const int32_t *outer_active, void *lx, void *lu, void *res_prev,
                                              int32_t *iters, hipStream_t s);
+
+// Trajectories per wavefront for the slot kernels (env override for tuning experiments).
+inline int pick_tpw(int B, int max_tpw, const char *env)
+{
+    int tpw = max_tpw;       // measured on MI355X (B=4096): fuller wavefronts win, the per-step latency does not shrink with fewer slots
+    (void)B;
+    if (const char *e = getenv(env)) tpw = atoi(e);
+    if (tpw < 1) tpw = 1;
+    return tpw > max_tpw ? max_tpw : tpw;
+}
 
 inline int check_launch()
 {

@@ -115,6 +115,18 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinP<T> p)
         for (int e = lane; e < N * n * m; e += kWave) Bm[e] = par[n * n + e % (n * m)];
         return;
     }
+    if (p.model == ISLS_MODEL_DI) {
+        const int d = n / 2;
+        for (int e = lane; e < N * n * n; e += kWave) {
+            const int r = (e % (n * n)) / n, c = e % n;
+            A[e] = (r == c) ? T(1) : ((r < d && c == r + d) ? par[0] : T(0));
+        }
+        for (int e = lane; e < N * n * m; e += kWave) {
+            const int r = (e % (n * m)) / m, c = e % m;
+            Bm[e] = (r == c) ? par[1] : ((r == c + d) ? par[2] : T(0));
+        }
+        return;
+    }
     const T dt = par[0];
     if (p.model == ISLS_MODEL_ARM3R) {
         // phase 1: J(q + qd dt + u dt^2/2) per step: tab[t] = {J00,J01,J02,J10,J11,J12}
@@ -182,10 +194,11 @@ template <typename T>
 int launch_linearize(const isls_linearize_args &a, hipStream_t s)
 {
     if (a.B < 0 || a.N < 1 || !a.model_par || !a.A || !a.Bm) return ISLS_ERR_ARG;
-    if (a.model != ISLS_MODEL_LTI && (!a.xhat || !a.uhat)) return ISLS_ERR_ARG;
+    if (a.model != ISLS_MODEL_LTI && a.model != ISLS_MODEL_DI && (!a.xhat || !a.uhat)) return ISLS_ERR_ARG;
     if (a.model == ISLS_MODEL_ARM3R && !(a.n == 9 && a.m == 3)) return ISLS_ERR_UNSUPPORTED;
     if (a.model == ISLS_MODEL_CAR && !(a.n == 4 && a.m == 2)) return ISLS_ERR_UNSUPPORTED;
-    if (a.model < ISLS_MODEL_LTI || a.model > ISLS_MODEL_CAR) return ISLS_ERR_UNSUPPORTED;
+    if (a.model == ISLS_MODEL_DI && !(a.n == 2 * a.m)) return ISLS_ERR_UNSUPPORTED;
+    if (a.model < ISLS_MODEL_LTI || a.model > ISLS_MODEL_DI) return ISLS_ERR_UNSUPPORTED;
     if ((size_t)a.N * 8 * sizeof(T) > 60000) return ISLS_ERR_UNSUPPORTED;
     if (a.B == 0) return ISLS_OK;
     LinP<T> p;

@@ -280,236 +280,5 @@ int launch_gain(const isls_gain_args &a, hipStream_t s)
 template int launch_gain<double>(const isls_gain_args &, hipStream_t);
 template int launch_gain<float>(const isls_gain_args &, hipStream_t);
 
-// ================================================================================================
-// Feed-forward pass
-// ================================================================================================
-template <typename T>
-struct FfP {
-    int B, N, mode;
-    View<T> A, Bm, c0x, c0u, Qr, Rr;
-    const T *xhat, *uhat, *zx, *lx, *zu, *lu;
-    const T *K, *Quu, *fac, *Qux;
-    T *k;
-    const int32_t *active;
-};
-
-template <typename T, int NX, int NU, int D>
-__global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
-{
-    constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
-    constexpr int AB_OFF = 0, K_OFF = AB_OFF + NX * W, QUX_OFF = K_OFF + NU * NX, QUU_OFF = QUX_OFF + NU * NX,
-                  FAC_OFF = QUU_OFF + NU * NU, D_OFF = FAC_OFF + NU * NU, V_OFF = D_OFF + W, QU_OFF = V_OFF + NX;
-    constexpr int SLOT = ((QU_OFF + NU) | 1);
-    constexpr int JA = (NX * NX + G - 1) / G, JB = (NX * NU + G - 1) / G, JK = (NU * NX + G - 1) / G,
-                  JU = (NU * NU + G - 1) / G;
-    __shared__ T lds[TPW * SLOT];
-
-    const int lane = threadIdx.x;
-    const int s = lane / G, i = lane - s * G;
-    const int b = blockIdx.x * TPW + s;
-    const bool inslot = s < TPW;
-    const bool valid = inslot && b < p.B && (p.active == nullptr || p.active[b] != 0);
-    const int N = p.N;
-    const int bb = valid ? b : 0;
-    T *rec = lds + (inslot ? s : TPW - 1) * SLOT;
-    T *ABs = rec + AB_OFF, *Ks = rec + K_OFF, *Quxs = rec + QUX_OFF, *Quus = rec + QUU_OFF, *Facs = rec + FAC_OFF,
-      *Ds = rec + D_OFF, *Vs = rec + V_OFF, *Qus = rec + QU_OFF;
-    const bool xl = i < NX;
-    const int iu = xl ? 0 : i - NX;
-    const int64_t bN = (int64_t)bb * N;
-    const bool hasx = p.Qr.p != nullptr, hasu = p.Rr.p != nullptr;
-    const bool hasreg = xl ? hasx : hasu;
-
-    // per-step staged operands: a ring of D steps in flight (this pass is HBM-bound: ~1 KB per step and
-    // trajectory against ~130 FMAs, so the loads must run several steps ahead of the recursion)
-    struct Stage {
-        T ra[JA], rb[JB], rk[JK], rq[JK], ruu[JU], rf[JU];
-        T c0, hv, zv, lv, rrow[NX];                        // own gradient entry, own xhat/z/lambda entry, own Qr/Rr row
-    };
-    Stage ring[D];
-    auto fetch = [&](int t, bool factors, Stage &g) {
-        const int64_t o = bN + t;
-        if (factors) {
-            coop_load<NX * NX, G>(p.A.at(bb, t), g.ra, i, valid);
-            coop_load<NX * NU, G>(p.Bm.at(bb, t), g.rb, i, valid);
-            coop_load<NU * NX, G>(p.K + o * NU * NX, g.rk, i, valid);
-            coop_load<NU * NX, G>(p.Qux + o * NU * NX, g.rq, i, valid);
-            coop_load<NU * NU, G>(p.Quu + o * NU * NU, g.ruu, i, valid);
-            coop_load<NU * NU, G>(p.fac + o * NU * NU, g.rf, i, valid);
-        }
-        // raw, unconditional loads only (see coop_load): own gradient entry, own xhat/z/lambda entry and own
-        // row of Qr/Rr, all through per-lane pointers; masking and arithmetic happen when the step consumes them
-        g.c0 = xl ? p.c0x.at(bb, t)[i] : p.c0u.at(bb, t)[iu];
-        if (hasreg) {
-            const int64_t e = xl ? o * NX + i : o * NU + iu;
-            g.zv = (xl ? p.zx : p.zu)[e];
-            g.lv = (xl ? p.lx : p.lu)[e];
-            const T *hat = xl ? p.xhat : p.uhat;
-            g.hv = hat ? hat[e] : T(0);
-            const T *q = xl ? p.Qr.at(bb, t) + i * NX : p.Rr.at(bb, t) + iu * NU;
-            const int lim = xl ? NX : NU;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) g.rrow[j] = q[j < lim ? j : lim - 1];
-        } else {
-            g.hv = g.zv = g.lv = T(0);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) g.rrow[j] = T(0);
-        }
-    };
-    // cx_i / cu_i = c0 + 2 * (row of Qr/Rr) . d       (isls/sls.py:132-137; O2 of SURVEY 8c)
-    auto reg_grad = [&](T c0v, const T (&row)[NX]) -> T {
-        // one fully unrolled loop with a select (two loops of different trip counts under a lane-dependent
-        // branch get merged into a runtime-trip-count loop, which sends `row` to scratch memory)
-        const int off = xl ? 0 : NX, lim = xl ? NX : NU;
-        T sacc = T(0);
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const T dj = Ds[off + j];                          // j >= lim reads a neighbour word, discarded below
-            sacc += (j < lim) ? row[j] * dj : T(0);
-        }
-        return hasreg ? c0v + T(2) * sacc : c0v;
-    };
-
-    // ---- terminal step: v = cx[N-1], k[N-1] = 0 ------------------------------------------------------
-    {
-        Stage term;
-        fetch(N - 1, false, term);
-        if (valid) Ds[i] = hasreg ? term.hv - (term.zv - term.lv) : T(0);
-        slot_sync();   
-        const T cterm = reg_grad(term.c0, term.rrow);
-        if (valid && xl) Vs[i] = cterm;
-        if (valid && !xl) p.k[(bN + N - 1) * NU + iu] = T(0);
-    }
-    slot_sync();   
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        fetch(N - 2 - d > 0 ? N - 2 - d : 0, true, ring[d]);    // unconditional (clamped): exact vmcnt bookkeeping
-
-    auto step = [&](int t, Stage &g) {
-        // stage the prefetched operands of step t
-#pragma unroll
-        for (int j = 0; j < JA; ++j) {
-            const int e = i + G * j;
-            if (valid && e < NX * NX) ABs[(e / NX) * W + (e % NX)] = g.ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            const int e = i + G * j;
-            if (valid && e < NX * NU) ABs[(e / NU) * W + NX + (e % NU)] = g.rb[j];
-        }
-        coop_put<NU * NX, G>(Ks, g.rk, i, valid);
-        coop_put<NU * NX, G>(Quxs, g.rq, i, valid);
-        coop_put<NU * NU, G>(Quus, g.ruu, i, valid);
-        coop_put<NU * NU, G>(Facs, g.rf, i, valid);
-        if (valid) Ds[i] = hasreg ? g.hv - (g.zv - g.lv) : T(0);     // xhat - (z - lambda)
-        const T c0_now = g.c0;
-        T row_now[NX];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) row_now[j] = g.rrow[j];
-        slot_sync();                                          // (a) record + v of the previous step visible
-        fetch(t - D > 0 ? t - D : 0, true, g);                 // refill this ring entry (clamped, unconditional)
-
-        // q_i = c_i + ([A B]' v)_i        (isls.py:285-286)
-        const T ci = reg_grad(c0_now, row_now);
-        T sacc = T(0);
-#pragma unroll
-        for (int k = 0; k < NX; ++k) sacc += ABs[k * W + i] * Vs[k];
-        const T qi = ci + sacc;
-        if (valid && !xl) Qus[iu] = qi;
-        slot_sync();                                          // (b) qu visible
-
-        // k_t = -Quu^{-1} qu  (every lane), then v_i for x-lanes
-        T qu[NU], kt[NU];
-#pragma unroll
-        for (int r = 0; r < NU; ++r) qu[r] = Qus[r];
-        if (p.mode == ISLS_SOLVE_CHOL) {
-            T U[NU][NU], rd[NU], x[NU];
-#pragma unroll
-            for (int r = 0; r < NU; ++r) {
-#pragma unroll
-                for (int c = 0; c < NU; ++c) U[r][c] = Facs[r * NU + c];
-                rd[r] = Facs[r * NU + r];
-            }
-            chol_solve<NU>(U, rd, qu, x);
-#pragma unroll
-            for (int r = 0; r < NU; ++r) kt[r] = -x[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < NU; ++r) {
-                T acc = T(0);
-#pragma unroll
-                for (int c = 0; c < NU; ++c) acc += Facs[r * NU + c] * qu[c];
-                kt[r] = -acc;
-            }
-        }
-        T vnew = T(0);
-        if (xl) {
-            T t_kqu = T(0), t_kquuk = T(0), t_quxk = T(0);
-            T Kc[NU];
-#pragma unroll
-            for (int r = 0; r < NU; ++r) { Kc[r] = Ks[r * NX + i]; t_kqu += Kc[r] * qu[r]; }
-#pragma unroll
-            for (int c = 0; c < NU; ++c) {
-                T w = T(0);
-#pragma unroll
-                for (int r = 0; r < NU; ++r) w += Kc[r] * Quus[r * NU + c];
-                t_kquuk += w * kt[c];
-            }
-#pragma unroll
-            for (int r = 0; r < NU; ++r) t_quxk += Quxs[r * NX + i] * kt[r];
-            vnew = (p.mode == ISLS_SOLVE_CHOL) ? ((qi + t_kqu) + t_kquuk) + t_quxk      // isls.py:302
-                                               : ((qi + t_quxk) + t_kqu) + t_kquuk;     // sls.py:200
-        } else if (valid) {
-            // one predicated store per row (a select chain over kt[] gets turned into a runtime-indexed
-            // private array, i.e. scratch memory)
-#pragma unroll
-            for (int r = 0; r < NU; ++r)
-                if (iu == r) p.k[(bN + t) * NU + r] = kt[r];
-        }
-        slot_sync();                                          // (c) everyone has read v
-        if (valid && xl) Vs[i] = vnew;
-    };
-
-    // full groups of D steps run branch-free (every VMEM op of the steady state is unconditional, so the
-    // compiler's vmcnt bookkeeping is exact and D steps of loads really stay in flight); then the remainder
-    int tb = N - 2;
-    for (; tb - (D - 1) >= 0; tb -= D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) step(tb - d, ring[d]);
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (tb - d >= 0) step(tb - d, ring[d]);
-}
-
-template <typename T>
-int launch_ff(const isls_ff_args &a, hipStream_t s)
-{
-    if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.c0x.p || !a.c0u.p || !a.K || !a.Quu || !a.fac || !a.Qux || !a.k)
-        return ISLS_ERR_ARG;
-    if (a.Qr.p && (!a.zx || !a.lx)) return ISLS_ERR_ARG;
-    if (a.Rr.p && (!a.zu || !a.lu)) return ISLS_ERR_ARG;
-    if (a.solve_mode != ISLS_SOLVE_CHOL && a.solve_mode != ISLS_SOLVE_INV) return ISLS_ERR_ARG;
-    if (a.B == 0) return ISLS_OK;
-    FfP<T> p;
-    p.B = a.B; p.N = a.N; p.mode = a.solve_mode;
-    p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.c0x = View<T>(a.c0x); p.c0u = View<T>(a.c0u);
-    p.Qr = View<T>(a.Qr); p.Rr = View<T>(a.Rr);
-    p.xhat = (const T *)a.xhat; p.uhat = (const T *)a.uhat;
-    p.zx = (const T *)a.zx; p.lx = (const T *)a.lx; p.zu = (const T *)a.zu; p.lu = (const T *)a.lu;
-    p.K = (const T *)a.K; p.Quu = (const T *)a.Quu; p.fac = (const T *)a.fac; p.Qux = (const T *)a.Qux;
-    p.k = (T *)a.k; p.active = a.active;
-#define CALL(NX_, NU_)                                                                                 \
-    {                                                                                                  \
-        constexpr int TPW = kWave / (NX_ + NU_);                                                       \
-        const int grid = (a.B + TPW - 1) / TPW;                                                        \
-        hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth>), dim3(grid), dim3(64), 0, s, p);  \
-    }
-    ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
-#undef CALL
-    return check_launch();
-}
-template int launch_ff<double>(const isls_ff_args &, hipStream_t);
-template int launch_ff<float>(const isls_ff_args &, hipStream_t);
 
 }  // namespace isls

@@ -6,10 +6,16 @@
 //
 // Mapping: one 64-lane wavefront per workgroup, cut into TPW = 64/GL slots (GL = max(L,8) lanes);
 // slot s owns trajectory blockIdx.x*TPW+s and lane c of the slot owns line-search candidate c (its
-// state x lives in registers for the whole horizon).  The per-step operands shared by the candidates
-// of a trajectory (K_t, k_t, xhat_t, uhat_t, the ADMM targets z-lambda and AL weights) are fetched by
-// the slot's lanes one element each, ONE STEP AHEAD, into a double-buffered LDS record and read back
-// as broadcasts.  After the arg-min the slot replays the winning step size and streams x_t,u_t out.
+// state x lives in registers for the whole horizon).
+//   SEARCH  : the per-step operands shared by the candidates of a trajectory (K_t, k_t, xhat_t, uhat_t, the
+//             ADMM targets z-lambda and the AL weights) are fetched by the slot's lanes one element each,
+//             D steps ahead (register ring, unconditional loads), into a double-buffered LDS record and read
+//             back as broadcasts.  Every S steps each candidate drops its state into an LDS checkpoint.
+//   ARG-MIN : first minimum over the slot's candidates (numpy NaN semantics, optional NaN rule/accept test).
+//   WINNER  : the reference returns x_noms[ind]; re-running the winner sequentially would cost another N
+//             dependent steps, so the horizon is cut into NSEG segments of S steps and lane c < NSEG replays
+//             segment c from the winner's checkpoint: N/NSEG dependent steps instead of N (the kernels are
+//             bound by the latency of the per-step chain, not by throughput).
 #include <type_traits>
 
 #include "isls_common.hpp"
@@ -18,7 +24,7 @@ namespace isls {
 
 template <typename T>
 struct RoP {
-    int B, N, L, flags;
+    int B, N, L, flags, nseg, seg_len;
     const T *par;
     int64_t par_sb;
     const T *K, *k, *xhat, *uhat, *x0, *alphas;
@@ -39,16 +45,15 @@ struct Model;
 
 template <typename T, int NX, int NU>
 struct Model<T, NX, NU, ISLS_MODEL_LTI> {      // x+ = A x + B u   (isls/sls_base.py:49-53)
-    T A[NX][NX], Bm[NX][NU];
-    __device__ __forceinline__ void load(const T *par)
+    // [A B] lives in the slot's LDS (NX x (NX+NU) words, read back as broadcasts): 54 doubles in registers per
+    // lane would push the kernel past 256 VGPRs, i.e. down to one wavefront per SIMD
+    static constexpr int LDS_WORDS = NX * (NX + NU);
+    const T *ab;
+    __device__ __forceinline__ void load(const T *par, T *lds_words, int c, int GL)
     {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) A[i][j] = par[i * NX + j];
-#pragma unroll
-            for (int j = 0; j < NU; ++j) Bm[i][j] = par[NX * NX + i * NU + j];
-        }
+        for (int e = c; e < NX * NX; e += GL) lds_words[(e / NX) * (NX + NU) + e % NX] = par[e];
+        for (int e = c; e < NX * NU; e += GL) lds_words[(e / NU) * (NX + NU) + NX + e % NU] = par[NX * NX + e];
+        ab = lds_words;
     }
     __device__ __forceinline__ void step(const T (&x)[NX], const T (&u)[NU], T (&xn)[NX]) const
     {
@@ -56,18 +61,35 @@ struct Model<T, NX, NU, ISLS_MODEL_LTI> {      // x+ = A x + B u   (isls/sls_bas
         for (int i = 0; i < NX; ++i) {
             T s = T(0), r = T(0);
 #pragma unroll
-            for (int j = 0; j < NX; ++j) s += A[i][j] * x[j];
+            for (int j = 0; j < NX; ++j) s += ab[i * (NX + NU) + j] * x[j];
 #pragma unroll
-            for (int j = 0; j < NU; ++j) r += Bm[i][j] * u[j];
+            for (int j = 0; j < NU; ++j) r += ab[i * (NX + NU) + NX + j] * u[j];
             xn[i] = s + r;
+        }
+    }
+};
+
+template <typename T, int NX, int NU>
+struct Model<T, NX, NU, ISLS_MODEL_DI> {       // double integrator through its Kronecker structure (see isls_hip.h)
+    static_assert(NX == 2 * NU, "double integrator: n = 2 d, m = d");
+    static constexpr int LDS_WORDS = 0;
+    T a, b0, b1;
+    __device__ __forceinline__ void load(const T *par, T *, int, int) { a = par[0]; b0 = par[1]; b1 = par[2]; }
+    __device__ __forceinline__ void step(const T (&x)[NX], const T (&u)[NU], T (&xn)[NX]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            xn[i] = (x[i] + a * x[NU + i]) + b0 * u[i];
+            xn[NU + i] = x[NU + i] + b1 * u[i];
         }
     }
 };
 
 template <typename T>
 struct Model<T, 9, 3, ISLS_MODEL_ARM3R> {      // planar 3R arm, state [q, qd, ee]  (3DoF notebooks cell 9)
+    static constexpr int LDS_WORDS = 0;
     T dt;
-    __device__ __forceinline__ void load(const T *par) { dt = par[0]; }
+    __device__ __forceinline__ void load(const T *par, T *, int, int) { dt = par[0]; }
     __device__ __forceinline__ void step(const T (&x)[9], const T (&u)[3], T (&xn)[9]) const
     {
         T c = T(0), ex = T(0), ey = T(0);
@@ -88,8 +110,9 @@ struct Model<T, 9, 3, ISLS_MODEL_ARM3R> {      // planar 3R arm, state [q, qd, e
 
 template <typename T>
 struct Model<T, 4, 2, ISLS_MODEL_CAR> {        // car-simple [x, y, theta, v]  (Car notebooks cell 6)
+    static constexpr int LDS_WORDS = 0;
     T dt;
-    __device__ __forceinline__ void load(const T *par) { dt = par[0]; }
+    __device__ __forceinline__ void load(const T *par, T *, int, int) { dt = par[0]; }
     __device__ __forceinline__ void step(const T (&x)[4], const T (&u)[2], T (&xn)[4]) const
     {
         xn[0] = x[0] + dt * x[3] * cos(x[2]);
@@ -99,123 +122,148 @@ struct Model<T, 4, 2, ISLS_MODEL_CAR> {        // car-simple [x, y, theta, v]  (
     }
 };
 
-constexpr int kRolloutDepth = 6;   // steps of record elements in flight per lane
+constexpr int kRolloutDepth = 3;   // steps of record elements in flight per lane
+constexpr int kMaxSeg = 10;        // winner replay: at most this many segments
 
-template <typename T, int NX, int NU, int MODEL>
-__global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
+template <int NX, int NU>
+struct RoLayout {
+    // record (elements): K | xh | rx | wq | k | uh | ru | wr | dump
+    static constexpr int O_K = 0, O_XH = O_K + NU * NX, O_RX = O_XH + NX, O_WQ = O_RX + NX, O_KK = O_WQ + NX,
+                         O_UH = O_KK + NU, O_RU = O_UH + NU, O_WR = O_RU + NU, REC = O_WR + NU, O_DUMP = REC,
+                         RECP = ((REC + 1) | 1);
+    // slot (elements): 2 records | aug[GL] | plain[GL] | model | checkpoints [L+1][nseg][NX] (row L: dump for idle lanes)
+    static constexpr int MDL = NX * (NX + NU);                 // model words of the slot ([A B] of an LTI model)
+    __host__ __device__ static constexpr int slot_elems(int L, int GL, int nseg) { return 2 * RECP + 2 * GL + MDL + (L + 1) * nseg * NX + 1; }
+};
+
+template <typename T, int NX, int NU, int MODEL, int GLMIN>
+__global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
 {
+    using LY = RoLayout<NX, NU>;
     constexpr int D = kRolloutDepth;
-    // record layout (doubles): K | xh | rx | wq | k | uh | ru | wr
-    constexpr int O_K = 0, O_XH = O_K + NU * NX, O_RX = O_XH + NX, O_WQ = O_RX + NX, O_KK = O_WQ + NX,
-                  O_UH = O_KK + NU, O_RU = O_UH + NU, O_WR = O_RU + NU, REC = O_WR + NU;
-    constexpr int MINGL = 8, MAXJ = (REC + MINGL - 1) / MINGL, MAXTPW = kWave / MINGL;
-    constexpr int OUTW = NX + NU;
-    constexpr int SLOT = 2 * REC + 2 * OUTW + 2 * kWave;      // 2 records, 2 out buffers, aug[] + plain[] costs
-    __shared__ T lds[MAXTPW * SLOT];
+    constexpr int O_K = LY::O_K, O_XH = LY::O_XH, O_RX = LY::O_RX, O_WQ = LY::O_WQ, O_KK = LY::O_KK, O_UH = LY::O_UH,
+                  O_RU = LY::O_RU, O_WR = LY::O_WR, REC = LY::REC, O_DUMP = LY::O_DUMP, RECP = LY::RECP;
+    constexpr int JM = (REC + GLMIN - 1) / GLMIN;              // record elements per lane
+    extern __shared__ __align__(16) unsigned char ro_smem[];
+    T *lds = reinterpret_cast<T *>(ro_smem);
 
-    const int L = p.L, N = p.N;
-    const int GL = L > MINGL ? L : MINGL, TPW = kWave / GL;
+    const int L = p.L, N = p.N, NSEG = p.nseg, S = p.seg_len;
+    const int GL = L > 8 ? L : 8, TPW = kWave / GL;
+    const int SLOT = LY::slot_elems(L, GL, NSEG);
     const int lane = threadIdx.x;
-    const int s = lane / GL, c = lane - s * GL;
+    // lanes beyond TPW*GL join the last slot as extra idle candidate lanes (c >= GL): they help nobody and
+    // write only dump words, but need no slot of their own
+    const int s = (lane / GL < TPW) ? lane / GL : TPW - 1, c = lane - s * GL;
     const int b = blockIdx.x * TPW + s;
-    const bool inslot = s < TPW;
-    const bool valid = inslot && b < p.B && (p.active == nullptr || p.active[b] != 0);
+    const bool inbatch = b < p.B;
+    const bool valid = inbatch && (p.active == nullptr || p.active[b] != 0);
     const bool cand = valid && c < L;
-    const int bb = valid ? b : 0;
+    const int bb = inbatch ? b : blockIdx.x * TPW;             // idle lanes shadow the block's first trajectory (loads only)
     const int64_t bN = (int64_t)bb * N;
-    T *slot = lds + (inslot ? s : TPW - 1) * SLOT;
-    T *recs = slot, *outs = slot + 2 * REC, *c_aug = outs + 2 * OUTW, *c_pln = c_aug + kWave;
+    T *slot = lds + s * SLOT;
+    T *recs = slot, *c_aug = slot + 2 * RECP, *c_pln = c_aug + GL, *mdl = c_pln + GL, *ck = mdl + LY::MDL;
     const bool absolute = (p.flags & ISLS_RO_ABSOLUTE) != 0;
     const bool has_xh = !absolute && p.xhat != nullptr, has_uh = !absolute && p.uhat != nullptr;
     const bool has_wq = p.wq.p != nullptr, has_wr = p.wr.p != nullptr;
 
-    // ---- per-lane load plan for the record elements e = c + GL*j ------------------------------------
-    const T *pa[MAXJ], *pb[MAXJ];
-    int stp[MAXJ];
+    // ---- per-lane load plan for the record elements e = c + GL*j : source word(s), step stride, LDS word ---
+    // absent elements read K[b,0,0,0] with stride 0 (a valid word) and are zeroed when staged
+    const T *pa[JM], *pb[JM];
+    int stp[JM], dst[JM];
+    bool has_a[JM], has_b[JM];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int e = c + GL * j;
-        pa[j] = nullptr; pb[j] = nullptr; stp[j] = 0;
-        if (!valid || e >= REC) continue;
-        if (e < O_XH) { pa[j] = p.K + bN * NU * NX + e; stp[j] = NU * NX; }
-        else if (e < O_RX) { if (has_xh) { pa[j] = p.xhat + bN * NX + (e - O_XH); stp[j] = NX; } }
-        else if (e < O_WQ) { if (has_wq) { pa[j] = p.zx + bN * NX + (e - O_RX); pb[j] = p.lx + bN * NX + (e - O_RX); stp[j] = NX; } }
-        else if (e < O_KK) { if (has_wq) { pa[j] = p.wq.at(bb, 0) + (e - O_WQ); stp[j] = (int)p.wq.st; } }
-        else if (e < O_UH) { pa[j] = p.k + bN * NU + (e - O_KK); stp[j] = NU; }
-        else if (e < O_RU) { if (has_uh) { pa[j] = p.uhat + bN * NU + (e - O_UH); stp[j] = NU; } }
-        else if (e < O_WR) { if (has_wr) { pa[j] = p.zu + bN * NU + (e - O_RU); pb[j] = p.lu + bN * NU + (e - O_RU); stp[j] = NU; } }
-        else { if (has_wr) { pa[j] = p.wr.at(bb, 0) + (e - O_WR); stp[j] = (int)p.wr.st; } }
+    for (int j = 0; j < JM; ++j) {
+        const int e = c < GL ? c + GL * j : REC;               // extra idle lanes stage nothing
+        const T *a = nullptr, *bq = nullptr;
+        int st = 0;
+        if (e < O_XH) { a = p.K + bN * NU * NX + e; st = NU * NX; }
+        else if (e < O_RX) { if (has_xh) { a = p.xhat + bN * NX + (e - O_XH); st = NX; } }
+        else if (e < O_WQ) { if (has_wq) { a = p.zx + bN * NX + (e - O_RX); bq = p.lx + bN * NX + (e - O_RX); st = NX; } }
+        else if (e < O_KK) { if (has_wq) { a = p.wq.at(bb, 0) + (e - O_WQ); st = (int)p.wq.st; } }
+        else if (e < O_UH) { a = p.k + bN * NU + (e - O_KK); st = NU; }
+        else if (e < O_RU) { if (has_uh) { a = p.uhat + bN * NU + (e - O_UH); st = NU; } }
+        else if (e < O_WR) { if (has_wr) { a = p.zu + bN * NU + (e - O_RU); bq = p.lu + bN * NU + (e - O_RU); st = NU; } }
+        else if (e < REC) { if (has_wr) { a = p.wr.at(bb, 0) + (e - O_WR); st = (int)p.wr.st; } }
+        has_a[j] = a != nullptr;
+        has_b[j] = bq != nullptr;
+        pa[j] = has_a[j] ? a : p.K + bN * NU * NX;
+        pb[j] = has_b[j] ? bq : pa[j];
+        stp[j] = has_a[j] ? st : 0;
+        dst[j] = (c < GL && e < REC) ? e : O_DUMP;
     }
-    // ring of D steps of record elements in flight per lane (HBM latency >> one step of math)
-    // Loads are raw and unconditional (absent elements point at K[b,0,0,0], a valid word, with stride 0) so
-    // that no branch and no arithmetic sits behind a load; z - lambda and the masking happen in put().
     struct Stage {
-        T a[MAXJ], b[MAXJ];
+        T a[JM], b[JM];
     };
-    bool has_a[MAXJ], has_b[MAXJ];
+    auto fetch = [&](int t, Stage &g) {                       // raw, unconditional loads (no use of the results here)
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        has_a[j] = pa[j] != nullptr;
-        has_b[j] = pb[j] != nullptr;
-        if (!has_a[j]) { pa[j] = p.K + bN * NU * NX; stp[j] = 0; }
-        if (!has_b[j]) pb[j] = pa[j];
-    }
-    auto fetch = [&](int t, Stage &g) {
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
+        for (int j = 0; j < JM; ++j) {
             const int64_t o = (int64_t)t * stp[j];
             g.a[j] = pa[j][o];
-            if (has_b[j]) g.b[j] = pb[j][o];                    // only the z/lambda pairs carry a second word
+            g.b[j] = pb[j][o];
         }
     };
-    auto put = [&](T *rec, const Stage &g) {
+    auto put = [&](T *rec, const Stage &g) {                  // unconditional ds_writes (dump word for surplus)
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int e = c + GL * j;
-            const T v = has_a[j] ? (has_b[j] ? g.a[j] - g.b[j] : g.a[j]) : T(0);      // z - lambda
-            if (valid && e < REC) rec[e] = v;
-        }
+        for (int j = 0; j < JM; ++j) rec[dst[j]] = has_a[j] ? (has_b[j] ? g.a[j] - g.b[j] : g.a[j]) : T(0);   // z - lambda
     };
 
     Model<T, NX, NU, MODEL> model;
-    model.load(p.par + (int64_t)bb * p.par_sb);
+    model.load(p.par + (int64_t)bb * p.par_sb, mdl, c < GL ? c : 0, GL);
+    slot_sync();
     const T *Qtab = p.Qtab + (int64_t)bb * p.Qtab_sb, *ztab = p.ztab + (int64_t)bb * p.ztab_sb;
     const T ustd = p.u_std;
-    T x_init[NX];
-#pragma unroll
-    for (int j = 0; j < NX; ++j) x_init[j] = p.x0 ? p.x0[(int64_t)bb * NX + j] : (p.xhat ? p.xhat[bN * NX + j] : T(0));
+    const T *x0p = p.x0 ? p.x0 + (int64_t)bb * NX : (p.xhat ? p.xhat + bN * NX : nullptr);
 
-    // step t of the winner, staged in LDS by lane 0 of the slot, leaves as one contiguous store per array
-    auto stream_out = [&](int t) {
-#pragma unroll
-        for (int j = 0; j < (OUTW + MINGL - 1) / MINGL; ++j) {
-            const int e = c + GL * j;
-            if (valid && e < OUTW) {
-                const T v = outs[(t & 1) * OUTW + e];
-                if (e < NX) p.x_out[(bN + t) * NX + e] = v;
-                else p.u_out[(bN + t) * NU + (e - NX)] = v;
-            }
-        }
+#ifdef ISLS_DIAG
+    unsigned long long racc[6] = {0, 0, 0, 0, 0, 0};
+#define RSTAMP_BEGIN unsigned long long tprev_ = __builtin_readcyclecounter();
+#define RSTAMP(k) { unsigned long long t1_ = __builtin_readcyclecounter(); racc[k] += t1_ - tprev_; tprev_ = t1_; }
+    const unsigned long long tstart_ = __builtin_readcyclecounter();
+#else
+#define RSTAMP_BEGIN
+#define RSTAMP(k)
+#endif
+    // per-step "Q_t != 0" hints as ballot masks in SGPRs (a scalar load per step would sit on the critical path)
+    const bool use_mask = p.qnz != nullptr && N <= 256;
+    unsigned long long qm0 = ~0ull, qm1 = ~0ull, qm2 = ~0ull, qm3 = ~0ull;
+    if (use_mask) {
+        qm0 = __ballot(lane < N && p.qnz[lane] != 0);
+        qm1 = __ballot(lane + 64 < N && p.qnz[lane + 64 < N ? lane + 64 : 0] != 0);
+        qm2 = __ballot(lane + 128 < N && p.qnz[lane + 128 < N ? lane + 128 : 0] != 0);
+        qm3 = __ballot(lane + 192 < N && p.qnz[lane + 192 < N ? lane + 192 : 0] != 0);
+    }
+    auto q_nonzero_at = [&](int t) -> bool {
+        if (!use_mask) return p.qnz == nullptr || p.qnz[t] != 0;
+        const int w = t >> 6;
+        const unsigned long long m = w == 0 ? qm0 : (w == 1 ? qm1 : (w == 2 ? qm2 : qm3));
+        return ((m >> (t & 63)) & 1ull) != 0;
     };
-
-    // One pass over the horizon.  SEARCH: every candidate lane accumulates its costs.  Otherwise the
-    // slot replays alpha_w and streams the trajectory (or the kept nominal when `keep`) to x_out/u_out.
-    auto roll = [&](auto search_tag, T alpha, bool keep, T &cst, T &cu, T &ag) {
-        constexpr bool SEARCH = decltype(search_tag)::value;
-        T x[NX];
+    // ================================ SEARCH ==========================================================
+    const T alpha = absolute ? T(1) : p.alphas[c < L ? c : 0];
+    T x[NX];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) x[j] = x_init[j];
-        cst = T(0); cu = T(0); ag = T(0);
+    for (int j = 0; j < NX; ++j) x[j] = x0p ? x0p[j] : T(0);
+    T cst = T(0), cu = T(0), ag = T(0);
+    {
         Stage ring[D] = {};
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            fetch(d < N ? d : N - 1, ring[d]);                 // unconditional (clamped): exact vmcnt bookkeeping
+        for (int d = 0; d < D; ++d) fetch(d < N ? d : N - 1, ring[d]);
+        T *ckc = ck + (c < L ? c : L) * NSEG * NX;             // this candidate's checkpoints (row L = dump)
+        int next_ck = 0, seg = 0;
         auto step = [&](int t, Stage &g) {
-            T *rec = recs + (t & 1) * REC;
+            RSTAMP_BEGIN
+            T *rec = recs + (t & 1) * RECP;
             put(rec, g);
-            slot_sync();                                      // record(t) (and out(t-1)) visible
+            slot_sync();                                      // record(t) visible to the slot
+            RSTAMP(0)
             fetch(t + D < N ? t + D : N - 1, g);               // refill this ring entry (clamped, unconditional)
-            if (!SEARCH && t > 0) stream_out(t - 1);
+            RSTAMP(1)
+            if (t == next_ck) {                                // uniform: state of every candidate at a segment start
+#pragma unroll
+                for (int j = 0; j < NX; ++j) ckc[seg * NX + j] = x[j];
+                ++seg;
+                next_ck += S;
+            }
             // u = (x - xhat) K' + alpha k + uhat            (isls.py:328-329)
             T u[NU];
 #pragma unroll
@@ -225,41 +273,36 @@ __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
                 for (int j = 0; j < NX; ++j) acc += (x[j] - rec[O_XH + j]) * rec[O_K + r * NX + j];
                 u[r] = (acc + alpha * rec[O_KK + r]) + rec[O_UH + r];
             }
-            if (SEARCH) {
-                if (p.qnz == nullptr || p.qnz[t] != 0) {       // (x-z)'Q(x-z), skipped where Q_t == 0
-                    const T *Q = Qtab + (int64_t)p.seq[t] * NX * NX, *z = ztab + (int64_t)p.seq[t] * NX;
-                    T d[NX];
+            RSTAMP(2)
+            if (q_nonzero_at(t)) {                             // (x-z)'Q(x-z), skipped where Q_t == 0
+                const T *Q = Qtab + (int64_t)p.seq[t] * NX * NX, *z = ztab + (int64_t)p.seq[t] * NX;
+                T d[NX];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) d[j] = x[j] - z[j];
+                for (int j = 0; j < NX; ++j) d[j] = x[j] - z[j];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        T acc = T(0);
+                for (int i = 0; i < NX; ++i) {
+                    T acc = T(0);
 #pragma unroll
-                        for (int j = 0; j < NX; ++j) acc += Q[i * NX + j] * d[j];
-                        cst += d[i] * acc;
-                    }
+                    for (int j = 0; j < NX; ++j) acc += Q[i * NX + j] * d[j];
+                    cst += d[i] * acc;
                 }
-#pragma unroll
-                for (int r = 0; r < NU; ++r) cu += u[r] * (ustd * u[r]);
-                if (has_wq) {
-#pragma unroll
-                    for (int j = 0; j < NX; ++j) { const T d = x[j] - rec[O_RX + j]; ag += (d * d) * rec[O_WQ + j]; }
-                }
-                if (has_wr) {
-#pragma unroll
-                    for (int r = 0; r < NU; ++r) { const T d = u[r] - rec[O_RU + r]; ag += (d * d) * rec[O_WR + r]; }
-                }
-            } else if (c == 0 && valid) {
-                T *o = outs + (t & 1) * OUTW;
-#pragma unroll
-                for (int j = 0; j < NX; ++j) o[j] = keep ? rec[O_XH + j] : x[j];
-#pragma unroll
-                for (int r = 0; r < NU; ++r) o[NX + r] = keep ? rec[O_UH + r] : u[r];
             }
+#pragma unroll
+            for (int r = 0; r < NU; ++r) cu += u[r] * (ustd * u[r]);
+            if (has_wq) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) { const T d = x[j] - rec[O_RX + j]; ag += (d * d) * rec[O_WQ + j]; }
+            }
+            if (has_wr) {
+#pragma unroll
+                for (int r = 0; r < NU; ++r) { const T d = u[r] - rec[O_RU + r]; ag += (d * d) * rec[O_WR + r]; }
+            }
+            RSTAMP(3)
             T xn[NX];
             model.step(x, u, xn);                              // x = f(x, u)   (isls.py:332)
 #pragma unroll
             for (int j = 0; j < NX; ++j) x[j] = xn[j];
+            RSTAMP(4)
         };
         int tb = 0;
         for (; tb + D <= N; tb += D) {                         // full groups: branch-free, exact vmcnt bookkeeping
@@ -269,18 +312,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (tb + d < N) step(tb + d, ring[d]);
-        slot_sync();   
-        if (!SEARCH) stream_out(N - 1);
-    };
+    }
 
-    // ---- search pass --------------------------------------------------------------------------------
-    const T my_alpha = absolute ? T(1) : ((c < L) ? p.alphas[c] : T(0));
-    T cst, cu, ag;
-    roll(std::true_type{}, my_alpha, false, cst, cu, ag);
+#ifdef ISLS_DIAG
+    const unsigned long long tsearch_ = __builtin_readcyclecounter();
+#endif
+    // ================================ ARG-MIN =========================================================
     const T plain = cst + cu;                                  // sum over x, then += sum over u (sls_base.py:33-39)
     const T aug = plain + ag;
-    if (cand) { c_aug[c] = aug; c_pln[c] = plain; }
-    slot_sync();   
+    if (c < GL) { c_aug[c] = aug; c_pln[c] = plain; }          // lanes L <= c < GL write words nobody reads
+    slot_sync();
     // first arg-min with numpy's NaN semantics; optional costs[isnan] = 1e5 (isls.py:362)
     const bool nan_rule = (p.flags & ISLS_RO_NAN_TO_1E5) != 0;
     int ind = 0;
@@ -306,10 +347,55 @@ __global__ __launch_bounds__(64) void rollout_kernel(RoP<T> p)
             if (bits) atomicOr(&p.status[b], bits);
         }
     }
-    // ---- winner pass ----------------------------------------------------------------------------------
-    const T alpha_w = absolute ? T(1) : p.alphas[ind];
-    slot_sync();   
-    roll(std::false_type{}, alpha_w, !accept, cst, cu, ag);
+
+    // ================================ WINNER ==========================================================
+    // lane c < NSEG replays steps [c*S, min((c+1)*S, N)) of candidate `ind` from its checkpoint and streams
+    // x_t, u_t to HBM (or copies the kept nominal when the acceptance test failed)
+    if (valid && c < NSEG) {
+        const T alpha_w = absolute ? T(1) : p.alphas[ind];
+        const int t0 = c * S, t1 = (t0 + S < N) ? t0 + S : N;
+        T xw[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xw[j] = ck[(ind * NSEG + c) * NX + j];
+        const T *Kp = p.K + (bN + t0) * NU * NX, *kp = p.k + (bN + t0) * NU;
+        const T *xhp = p.xhat ? p.xhat + (bN + t0) * NX : nullptr, *uhp = p.uhat ? p.uhat + (bN + t0) * NU : nullptr;
+        T *xo = p.x_out + (bN + t0) * NX, *uo = p.u_out + (bN + t0) * NU;
+        for (int t = t0; t < t1; ++t) {
+            T Kt[NU * NX], kt[NU], xh[NX], uh[NU];
+#pragma unroll
+            for (int j = 0; j < NU * NX; ++j) Kt[j] = Kp[j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) kt[j] = kp[j];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) xh[j] = xhp ? xhp[j] : T(0);
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uh[j] = uhp ? uhp[j] : T(0);
+            T u[NU];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                T acc = T(0);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) acc += (xw[j] - (has_xh ? xh[j] : T(0))) * Kt[r * NX + j];
+                u[r] = (acc + alpha_w * kt[r]) + (has_uh ? uh[r] : T(0));
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) xo[j] = accept ? xw[j] : xh[j];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) uo[r] = accept ? u[r] : uh[r];
+            T xn[NX];
+            model.step(xw, u, xn);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) xw[j] = xn[j];
+            Kp += NU * NX; kp += NU; xo += NX; uo += NU;
+            if (xhp) xhp += NX;
+            if (uhp) uhp += NU;
+        }
+    }
+#ifdef ISLS_DIAG
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
+        printf("ro diag block %d: put+sync %llu fetch %llu u %llu cost %llu model %llu | search %llu winner %llu cycles (N=%d nseg=%d)\n",
+               blockIdx.x, racc[0], racc[1], racc[2], racc[3], racc[4], tsearch_ - tstart_, __builtin_readcyclecounter() - tsearch_, N, NSEG);
+#endif
 }
 
 template <typename T>
@@ -322,9 +408,6 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s)
     if ((a.flags & ISLS_RO_ACCEPT_TEST) && !a.cost_cur) return ISLS_ERR_ARG;
     if (a.wq.p && (!a.zx || !a.lx)) return ISLS_ERR_ARG;
     if (a.wr.p && (!a.zu || !a.lu)) return ISLS_ERR_ARG;
-    if (a.wq.sb != 0 || a.wr.sb != 0) {
-        /* per-trajectory AL weights are supported through the view's batch stride */
-    }
     if (a.B == 0) return ISLS_OK;
     RoP<T> p;
     p.B = a.B; p.N = a.N; p.L = a.L; p.flags = a.flags;
@@ -341,24 +424,39 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s)
     p.best = a.best; p.status = a.status; p.active = a.active;
     const int GL = a.L > 8 ? a.L : 8, TPW = kWave / GL;
     const int grid = (a.B + TPW - 1) / TPW;
-#define LAUNCH(NX_, NU_, MODEL_) \
-    hipLaunchKernelGGL((rollout_kernel<T, NX_, NU_, MODEL_>), dim3(grid), dim3(64), 0, s, p)
-    if (a.model == ISLS_MODEL_LTI) {
-        if (a.n == 6 && a.m == 3) LAUNCH(6, 3, ISLS_MODEL_LTI);
-        else if (a.n == 2 && a.m == 1) LAUNCH(2, 1, ISLS_MODEL_LTI);
-        else if (a.n == 4 && a.m == 2) LAUNCH(4, 2, ISLS_MODEL_LTI);
-        else if (a.n == 9 && a.m == 3) LAUNCH(9, 3, ISLS_MODEL_LTI);
-        else return ISLS_ERR_UNSUPPORTED;
-    } else if (a.model == ISLS_MODEL_ARM3R) {
-        if (a.n == 9 && a.m == 3) LAUNCH(9, 3, ISLS_MODEL_ARM3R);
-        else return ISLS_ERR_UNSUPPORTED;
-    } else if (a.model == ISLS_MODEL_CAR) {
-        if (a.n == 4 && a.m == 2) LAUNCH(4, 2, ISLS_MODEL_CAR);
-        else return ISLS_ERR_UNSUPPORTED;
-    } else {
-        return ISLS_ERR_UNSUPPORTED;
+    // winner replay geometry: NSEG segments of S steps, NSEG <= lanes of a slot
+    int nseg = GL < kMaxSeg ? GL : kMaxSeg;
+    if (nseg > a.N) nseg = a.N;
+    auto smem_bytes = [&](int ns) {
+        const int slot = (a.n == 6 ? RoLayout<6, 3>::slot_elems(a.L, GL, ns) : a.n == 2 ? RoLayout<2, 1>::slot_elems(a.L, GL, ns)
+                          : a.n == 4 ? RoLayout<4, 2>::slot_elems(a.L, GL, ns) : RoLayout<9, 3>::slot_elems(a.L, GL, ns));
+        return (size_t)TPW * slot * sizeof(T);
+    };
+    while (nseg > 1 && smem_bytes(nseg) > 20 * 1024) --nseg;   // <= 20 KB per wavefront keeps 8 workgroups per CU
+    p.seg_len = (a.N + nseg - 1) / nseg;
+    p.nseg = (a.N + p.seg_len - 1) / p.seg_len;                // drop empty trailing segments
+    const size_t smem = smem_bytes(p.nseg);
+    if (smem > 64 * 1024) return ISLS_ERR_UNSUPPORTED;
+#define LAUNCH_G(NX_, NU_, MODEL_, G_) \
+    hipLaunchKernelGGL((rollout_kernel<T, NX_, NU_, MODEL_, G_>), dim3(grid), dim3(64), smem, s, p)
+#define LAUNCH(NX_, NU_, MODEL_)                                     \
+    {                                                                \
+        if (GL >= 32) LAUNCH_G(NX_, NU_, MODEL_, 32);                \
+        else if (GL >= 16) LAUNCH_G(NX_, NU_, MODEL_, 16);           \
+        else LAUNCH_G(NX_, NU_, MODEL_, 8);                          \
     }
+    if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_LTI) LAUNCH(4, 2, ISLS_MODEL_LTI)
+    else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_CAR) LAUNCH(4, 2, ISLS_MODEL_CAR)
+    else if (a.n == 9 && a.m == 3 && a.model == ISLS_MODEL_LTI) LAUNCH(9, 3, ISLS_MODEL_LTI)
+    else if (a.n == 9 && a.m == 3 && a.model == ISLS_MODEL_ARM3R) LAUNCH(9, 3, ISLS_MODEL_ARM3R)
+    else if (a.n == 6 && a.m == 3 && a.model == ISLS_MODEL_LTI) LAUNCH(6, 3, ISLS_MODEL_LTI)
+    else if (a.n == 2 && a.m == 1 && a.model == ISLS_MODEL_LTI) LAUNCH(2, 1, ISLS_MODEL_LTI)
+    else if (a.n == 6 && a.m == 3 && a.model == ISLS_MODEL_DI) LAUNCH(6, 3, ISLS_MODEL_DI)
+    else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_DI) LAUNCH(4, 2, ISLS_MODEL_DI)
+    else if (a.n == 2 && a.m == 1 && a.model == ISLS_MODEL_DI) LAUNCH(2, 1, ISLS_MODEL_DI)
+    else return ISLS_ERR_UNSUPPORTED;
 #undef LAUNCH
+#undef LAUNCH_G
     return check_launch();
 }
 template int launch_rollout<double>(const isls_rollout_args &, hipStream_t);

@@ -20,7 +20,7 @@ except Exception:  # pragma: no cover
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
-MODEL_LTI, MODEL_ARM3R, MODEL_CAR = 0, 1, 2
+MODEL_LTI, MODEL_ARM3R, MODEL_CAR, MODEL_DI = 0, 1, 2, 3
 RO_NAN_TO_1E5, RO_ACCEPT_TEST, RO_ABSOLUTE = 1, 2, 4
 PROJ_NONE, PROJ_BOX = 0, 1
 
@@ -120,7 +120,7 @@ class IslsError(RuntimeError):
 
 def load_hip_library(path=None):
     """dlopen the HIP library; fail loudly (no CPU fallback exists by design)."""
-    path = path or HIP_LIB_PATH
+    path = path or os.environ.get("ISLS_HIP_LIB") or HIP_LIB_PATH       # env override: A/B builds when tuning
     if not os.path.exists(path):
         raise IslsError(f"{path} not found: build it with `python __graft_entry__.py` "
                         f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")

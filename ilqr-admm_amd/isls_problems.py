@@ -21,6 +21,7 @@ import numpy as np
 MODEL_LTI = 0
 MODEL_ARM3R = 1
 MODEL_CAR = 2
+MODEL_DI = 3
 
 
 # --------------------------------------------------------------------------------------------

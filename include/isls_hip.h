@@ -52,6 +52,11 @@ extern "C" {
 #define ISLS_MODEL_LTI 0    /* x+ = A x + B u ; par = [A(n*n), B(n*m)]            (isls/sls_base.py:49-53)       */
 #define ISLS_MODEL_ARM3R 1  /* planar 3R arm, n=9 m=3 ; par = [dt]                 (3DoF notebooks cells 9-10)    */
 #define ISLS_MODEL_CAR 2    /* car-simple, n=4 m=2 ; par = [dt]                    (Car notebooks cell 6)         */
+#define ISLS_MODEL_DI 3     /* double integrator, n=2d m=d: the LTI model of get_double_integrator_AB(d, 2, dt)
+                               (isls/utils.py:266-276) evaluated through its Kronecker structure
+                               A=[[I,aI],[0,I]], B=[[b0 I],[b1 I]]: p+ = p + a v + b0 u, v+ = v + b1 u;
+                               par = [a, b0, b1] = [A[0,d], B[0,0], B[d,0]]. Same values as ISLS_MODEL_LTI on
+                               those matrices (the skipped terms are exact zeros), a sixth of the multiplies */
 
 /* rollout flags */
 #define ISLS_RO_NAN_TO_1E5 1   /* costs[isnan] = 1e5            (iterate_once_dp only, isls/isls.py:362)          */

@@ -289,6 +289,12 @@ static void FN(model_step)(int model, const REAL *par, int n, int m, const REAL 
             for (int j = 0; j < m; ++j) r += Bm[i * m + j] * u[j];
             xn[i] = s + r;
         }
+    } else if (model == ISLS_MODEL_DI) { /* same LTI map through its Kronecker structure (isls/utils.py:266-276) */
+        const int d = n / 2;
+        for (int i = 0; i < d; ++i) {
+            xn[i] = (x[i] + par[0] * x[d + i]) + par[1] * u[i];
+            xn[d + i] = x[d + i] + par[2] * u[i];
+        }
     } else if (model == ISLS_MODEL_ARM3R) { /* 3DoF notebook cell 9 + closed-form FK */
         const REAL dt = par[0];
         REAL c = 0, ex = 0, ey = 0;
@@ -540,6 +546,10 @@ int FN(oracle_linearize)(const isls_linearize_args *a)
             if (a->model == ISLS_MODEL_LTI) {
                 for (int i = 0; i < n * n; ++i) A[i] = par[i];
                 for (int i = 0; i < n * m; ++i) Bm[i] = par[n * n + i];
+            } else if (a->model == ISLS_MODEL_DI) {
+                const int d = n / 2;
+                for (int i = 0; i < n; ++i) A[i * n + i] = 1;
+                for (int i = 0; i < d; ++i) { A[i * n + d + i] = par[0]; Bm[i * m + i] = par[1]; Bm[(d + i) * m + i] = par[2]; }
             } else if (a->model == ISLS_MODEL_ARM3R) {
                 const REAL dt = par[0];
                 REAL q[3], c = 0, sn[3], cs[3];

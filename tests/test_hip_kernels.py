@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import isls_problems as P
+from helpers import ALPHAS as ALPHAS_
 from helpers import OracleDriver, problem_arrays
 from isls import _capi as capi
 
@@ -71,6 +72,37 @@ def test_rollout_candidate_counts(dual, L):
     d.gain(), d.ff()
     d.rollout(L, cost_all=np.zeros((11, L)))
     _report(dk)
+
+
+def test_double_integrator_model_equals_dense_lti(oracle):
+    """ISLS_MODEL_DI (Kronecker-structured evaluation) on the GPU against the dense LTI map of the oracle."""
+    import torch
+    from dual import hip_kernels
+    from isls import models
+    cfg = P.config2(batch=16, N=100, seed=5)
+    pa = problem_arrays(cfg, range(13))
+    d = OracleDriver(oracle, pa, rho_u=cfg["rho_u"])
+    d.linearize_expand()
+    d.gain(), d.ff()
+    cost_all = np.zeros((13, 20))
+    d.rollout(20, cost_all=cost_all)                          # oracle, dense LTI
+    mdl = models.LTI(cfg["A"], cfg["B"])
+    assert mdl.model_id == capi.MODEL_DI
+    hip = hip_kernels()
+    dev = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    xx, xu, ca, cn, best = dev(np.zeros_like(d.xx)), dev(np.zeros_like(d.xu)), dev(np.zeros((13, 20))), dev(np.zeros(13)), dev(np.zeros(13, dtype=np.int32))
+    hip.rollout_ls(mdl.model_id, dev(mdl.params()), dev(d.K), dev(d.k), dev(d.xhat), dev(d.uhat), dev(ALPHAS_[:20]),
+                   dev(pa["Qtab"]), dev(pa["ztab"]), dev(pa["seq"]), pa["u_std"], xx, xu, best=best, cost_new=cn, cost_all=ca,
+                   wr=dev(d.wr), zu=dev(d.zu), lu=dev(d.lu), cost_cur=dev(d.cost))
+    torch.cuda.synchronize()
+    assert np.max(np.abs(ca.cpu().numpy() - cost_all)) / max(1.0, np.abs(cost_all).max()) < 1e-12
+    assert np.array_equal(best.cpu().numpy(), d.best)
+    assert np.max(np.abs(xx.cpu().numpy() - d.xx)) < 1e-12 and np.max(np.abs(xu.cpu().numpy() - d.xu)) < 1e-12
+    # linearisation of the structured model reproduces the dense A, B
+    A, Bm = dev(np.zeros_like(d.A)), dev(np.zeros_like(d.Bm))
+    hip.linearize(mdl.model_id, dev(mdl.params()), dev(d.xhat), dev(d.uhat), A, Bm)
+    torch.cuda.synchronize()
+    assert np.array_equal(A.cpu().numpy(), d.A) and np.array_equal(Bm.cpu().numpy(), d.Bm)
 
 
 def test_arm_all_kernels(dual, golden):
