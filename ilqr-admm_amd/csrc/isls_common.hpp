@@ -15,6 +15,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/isls_hip.h"
 
 namespace isls {
@@ -29,6 +32,20 @@ struct View {
     __host__ __device__ explicit View(const isls_view &v) : p(static_cast<const T *>(v.p)), sb(v.sb), st(v.st) {}
     __device__ __forceinline__ const T *at(int b, int t) const { return p + (int64_t)b * sb + (int64_t)t * st; }
 };
+
+// Compile-time loop: body(integral_constant<int, j>) for j = 0..N-1.  `#pragma unroll` is only a hint and the
+// inliner/unroller gives up on some lambda bodies; a runtime index into a small per-lane array then sends the
+// array to scratch memory.  static_for makes every index a constant expression.
+template <int N, typename F, int... Js>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Js...>)
+{
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl<N>(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
 
 // Hand-off through LDS between the lanes of ONE wavefront (every recursive kernel here runs
 // single-wave workgroups).  DS instructions of a wave execute in issue order, so a ds_write followed by a

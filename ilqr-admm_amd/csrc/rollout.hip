@@ -171,8 +171,8 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
     const T *pa[JM], *pb[JM];
     int stp[JM], dst[JM];
     bool has_a[JM], has_b[JM];
-#pragma unroll
-    for (int j = 0; j < JM; ++j) {
+    static_for<JM>([&](auto J) {
+        constexpr int j = decltype(J)::value;
         const int e = c < GL ? c + GL * j : REC;               // extra idle lanes stage nothing
         const T *a = nullptr, *bq = nullptr;
         int st = 0;
@@ -190,21 +190,23 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
         pb[j] = has_b[j] ? bq : pa[j];
         stp[j] = has_a[j] ? st : 0;
         dst[j] = (c < GL && e < REC) ? e : O_DUMP;
-    }
+    });
     struct Stage {
         T a[JM], b[JM];
     };
     auto fetch = [&](int t, Stage &g) {                       // raw, unconditional loads (no use of the results here)
-#pragma unroll
-        for (int j = 0; j < JM; ++j) {
+        static_for<JM>([&](auto J) {
+            constexpr int j = decltype(J)::value;
             const int64_t o = (int64_t)t * stp[j];
             g.a[j] = pa[j][o];
             g.b[j] = pb[j][o];
-        }
+        });
     };
     auto put = [&](T *rec, const Stage &g) {                  // unconditional ds_writes (dump word for surplus)
-#pragma unroll
-        for (int j = 0; j < JM; ++j) rec[dst[j]] = has_a[j] ? (has_b[j] ? g.a[j] - g.b[j] : g.a[j]) : T(0);   // z - lambda
+        static_for<JM>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            rec[dst[j]] = has_a[j] ? (has_b[j] ? g.a[j] - g.b[j] : g.a[j]) : T(0);   // z - lambda
+        });
     };
 
     Model<T, NX, NU, MODEL> model;
@@ -223,17 +225,20 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
 #define RSTAMP_BEGIN
 #define RSTAMP(k)
 #endif
+    // kernel-argument fields used inside the step lambdas are copied to locals first: a lambda that captures the
+    // by-value argument struct by reference forces the whole struct into scratch memory
+    const int32_t *const seqp = p.seq, *const qnzp = p.qnz;
     // per-step "Q_t != 0" hints as ballot masks in SGPRs (a scalar load per step would sit on the critical path)
-    const bool use_mask = p.qnz != nullptr && N <= 256;
+    const bool use_mask = qnzp != nullptr && N <= 256;
     unsigned long long qm0 = ~0ull, qm1 = ~0ull, qm2 = ~0ull, qm3 = ~0ull;
     if (use_mask) {
-        qm0 = __ballot(lane < N && p.qnz[lane] != 0);
-        qm1 = __ballot(lane + 64 < N && p.qnz[lane + 64 < N ? lane + 64 : 0] != 0);
-        qm2 = __ballot(lane + 128 < N && p.qnz[lane + 128 < N ? lane + 128 : 0] != 0);
-        qm3 = __ballot(lane + 192 < N && p.qnz[lane + 192 < N ? lane + 192 : 0] != 0);
+        qm0 = __ballot(lane < N && qnzp[lane < N ? lane : 0] != 0);
+        qm1 = __ballot(lane + 64 < N && qnzp[lane + 64 < N ? lane + 64 : 0] != 0);
+        qm2 = __ballot(lane + 128 < N && qnzp[lane + 128 < N ? lane + 128 : 0] != 0);
+        qm3 = __ballot(lane + 192 < N && qnzp[lane + 192 < N ? lane + 192 : 0] != 0);
     }
     auto q_nonzero_at = [&](int t) -> bool {
-        if (!use_mask) return p.qnz == nullptr || p.qnz[t] != 0;
+        if (!use_mask) return qnzp == nullptr || qnzp[t] != 0;
         const int w = t >> 6;
         const unsigned long long m = w == 0 ? qm0 : (w == 1 ? qm1 : (w == 2 ? qm2 : qm3));
         return ((m >> (t & 63)) & 1ull) != 0;
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
     for (int j = 0; j < NX; ++j) x[j] = x0p ? x0p[j] : T(0);
     T cst = T(0), cu = T(0), ag = T(0);
     {
-        Stage ring[D] = {};
+        Stage ring[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) fetch(d < N ? d : N - 1, ring[d]);
         T *ckc = ck + (c < L ? c : L) * NSEG * NX;             // this candidate's checkpoints (row L = dump)
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
             }
             RSTAMP(2)
             if (q_nonzero_at(t)) {                             // (x-z)'Q(x-z), skipped where Q_t == 0
-                const T *Q = Qtab + (int64_t)p.seq[t] * NX * NX, *z = ztab + (int64_t)p.seq[t] * NX;
+                const T *Q = Qtab + (int64_t)seqp[t] * NX * NX, *z = ztab + (int64_t)seqp[t] * NX;
                 T d[NX];
 #pragma unroll
                 for (int j = 0; j < NX; ++j) d[j] = x[j] - z[j];
