@@ -30,7 +30,26 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-KIND_NAMES = ["riccati_gain_kernel", "riccati_ff_kernel", "rollout_kernel", "admm_update_kernel"]
+KIND_NAMES = ["riccati_gain_kernel", "riccati_ff_kernel", "rollout_kernel", "admm_update_kernel", "ff_prepare_kernel"]
+# kernels behind each timed family (isls_timing kind): the time-parallel feed-forward pass is two launches
+KIND_KERNELS = [["riccati_gain_kernel"], ["riccati_ff_kernel", "ff_stitch_kernel"], ["rollout_kernel"],
+                ["admm_update_kernel"], ["ff_prepare_kernel"]]
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+
+
+def pmc_traffic(kind):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (tools/pmc_traffic.py),
+    or None when no profile of this workload is available."""
+    try:
+        kernels = json.load(open(PMC_FILE))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    total, found = 0.0, False
+    for name, rec in kernels.items():
+        if "<double" in name and any(("isls::" + k + "<") in name for k in KIND_KERNELS[kind]):
+            total += rec["hbm_bytes"]
+            found = True
+    return total if found else None
 
 
 def algorithmic_bytes(n, m, N, w, has_x, has_u, lti):
@@ -41,7 +60,8 @@ def algorithmic_bytes(n, m, N, w, has_x, has_u, lti):
     ff = ab + 2 * m * n + 2 * m * m + (n + m) + reg + m               # A,B,K,Qux,Quu,fac,c0,reg in; k out
     ro = m * n + m + (n + m) + ((2 * n if has_x else 0) + (2 * m if has_u else 0)) + (n + m)   # K,k,nominal,z,l in; x,u out
     admm = (5 * n if has_x else 0) + (5 * m if has_u else 0)          # x,z,l in; z,l out
-    return [w * N * v for v in (gain, ff, ro, admm)]
+    prep = ab + 2 * m * n + 2 * m * m + m * n                         # A,B,K,Qux,Quu,fac in; G out (once per gain pass)
+    return [w * N * v for v in (gain, ff, ro, admm, prep)]
 
 
 def iteration_bytes(n, m, N, w):
@@ -130,7 +150,7 @@ def main():
 
     # ---- per-kernel-family durations from the HIP events recorded on the launch stream ------------
     fam = []
-    for kind in range(4):
+    for kind in range(5):
         cnt = ctypes.c_int(0)
         ms = lib.isls_timing_read_ms(kind, ctypes.byref(cnt))
         fam.append((ms, cnt.value))
@@ -141,6 +161,7 @@ def main():
         w = 8
         abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti)
         dom = int(np.argmax([ms for ms, _ in fam]))
+        default_workload = (B, N, J, L) == (4096, 100, 5, 20) and not args.lti
         avg_ms = fam[dom][0] / max(1, fam[dom][1])
         achieved = abytes[dom] * B / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         it_bytes = iteration_bytes(n, m, N, w) * B
@@ -152,15 +173,17 @@ def main():
             "config": {"workload": "config2: 3-D double integrator iLQR-ADMM (DP form), box constraint on u",
                        "batch_per_gpu": B, "horizon": N, "x_dim": n, "u_dim": m, "admm_iters_J": J,
                        "line_search_L": L, "layout": "LTI stride-0 A,B" if args.lti else "time-varying A,B per trajectory",
-                       "early_exit": False, "trajectory_iterations_per_s": it_per_s * B,
+                       "early_exit": False,
+                       "ff_time_parallel_segments": max(1, int(eng._outer_args.ff.seg.nseg)), "trajectory_iterations_per_s": it_per_s * B,
                        "admm_iterations_per_s": it_per_s * J},
             "roofline": {"bound": "hbm", "kernel": KIND_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(dom) if default_workload else None,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": abytes[dom] * B,
                          "iteration_algorithmic_bytes": it_bytes,
                          "iteration_frac": it_bytes * (it_per_s / world) / 1e9 / HBM_PEAK_GBS},
-            "kernels_ms_per_step": {KIND_NAMES[k]: fam[k][0] / args.steps for k in range(4)},
-            "launches_per_step": {KIND_NAMES[k]: fam[k][1] / args.steps for k in range(4)},
+            "kernels_ms_per_step": {KIND_NAMES[k]: fam[k][0] / args.steps for k in range(5)},
+            "launches_per_step": {KIND_NAMES[k]: fam[k][1] / args.steps for k in range(5)},
             "convergence": {"sum_cost": float(red_host[:, 0].sum()), "max_prim": float(red_host[:, 1].max()),
                             "max_dual": float(red_host[:, 2].max()), "active": float(red_host[:, 3].sum()),
                             "failed": float(red_host[:, 4].sum())},

@@ -10,9 +10,9 @@ namespace isls {
 // (bench.py reads these: average launch duration of the dominant kernel for the roofline line)
 struct Timing {
     bool on = false;
-    static constexpr int kKinds = 4;
+    static constexpr int kKinds = 5;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[kKinds];
-    size_t used[kKinds] = {0, 0, 0, 0};
+    size_t used[kKinds] = {0, 0, 0, 0, 0};
 };
 static Timing g_timing;
 
@@ -48,8 +48,19 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
     int rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, ad.iters, s);
     if (rc != ISLS_OK) return rc;
     if (!a.skip_gain) {
-        ScopedTimer tm(0, s);
-        if ((rc = launch_gain<T>(a.gain, s)) != ISLS_OK) return rc;
+        {
+            ScopedTimer tm(0, s);
+            if ((rc = launch_gain<T>(a.gain, s)) != ISLS_OK) return rc;
+        }
+        if (ff_seg_enabled(a.ff.seg)) {                        // operators of the time-parallel feed-forward pass
+            const isls_ff_args &f = a.ff;
+            isls_ff_prepare_args pr = {};
+            pr.B = f.B; pr.N = f.N; pr.n = f.n; pr.m = f.m; pr.solve_mode = f.solve_mode;
+            pr.A = f.A; pr.Bm = f.Bm; pr.K = f.K; pr.Quu = f.Quu; pr.fac = f.fac; pr.Qux = f.Qux;
+            pr.active = f.active; pr.seg = f.seg;
+            ScopedTimer tm(4, s);
+            if ((rc = launch_ff_prepare<T>(pr, s)) != ISLS_OK) return rc;
+        }
     }
     for (int j = 0; j < a.J; ++j) {
         {
@@ -95,6 +106,7 @@ using namespace isls;
 
 DEFINE_ENTRY(riccati_gain, isls_gain_args, launch_gain, 0)
 DEFINE_ENTRY(riccati_ff, isls_ff_args, launch_ff, 1)
+DEFINE_ENTRY(riccati_ff_prepare, isls_ff_prepare_args, launch_ff_prepare, 4)
 DEFINE_ENTRY(rollout_ls, isls_rollout_args, launch_rollout, 2)
 DEFINE_ENTRY(admm_update, isls_admm_args, launch_admm, 3)
 
@@ -139,6 +151,14 @@ ISLS_API int isls_ilqr_admm_outer_f64(const isls_outer_args *a, void *stream)
 ISLS_API int isls_ilqr_admm_outer_f32(const isls_outer_args *a, void *stream)
 {
     return a ? outer_iteration<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+
+ISLS_API int32_t isls_ff_segments(int32_t N, int32_t nseg_requested, int32_t *seg_len)
+{
+    int len = 0;
+    const int n = ff_segments(N, nseg_requested, &len);
+    if (seg_len) *seg_len = len;
+    return n;
 }
 
 ISLS_API int isls_version(void) { return ISLS_VERSION; }

@@ -14,15 +14,28 @@
 //     scaffolding around the ds_writes;
 //   * LDS hand-offs inside the wave use slot_sync() (no s_barrier, no vmcnt(0) drain of the ring);
 //   * two hand-offs per step: (a) record + v  ->  q ; (b) qu  ->  k, v'.
+//
+// The N-1 sequential steps are the real limit at the reference batch (585 wavefronts of 100 dependent steps on
+// 1024 SIMDs), so the pass also exists in a TIME-PARALLEL form (isls_ffseg in include/isls_hip.h): blockIdx.y
+// cuts the horizon into segments that recurse concurrently from v_in = 0, ff_stitch_kernel chains the true
+// segment inputs through the transfer matrices and adds G_t v_in to k_t, and ff_prepare_kernel produces those
+// operators once per gain pass by pushing the n unit vectors through the homogeneous recursion.
 #include "isls_common.hpp"
 
 namespace isls {
 
-constexpr int kFfDepth = 4;     // steps of operands in flight per lane
+constexpr int kFfDepth = 4;     // steps of operands in flight per lane (sequential form, <= 1 wave per SIMD)
+constexpr int kFfSegDepth = 2;  // ... in the time-parallel form, where kFfSegOcc co-resident waves hide the latency
+#ifndef ISLS_FF_SEG_OCC
+#define ISLS_FF_SEG_OCC 2
+#endif
+constexpr int kFfSegOcc = ISLS_FF_SEG_OCC;
 
 template <typename T>
 struct FfP {
     int B, N, mode, tpw;
+    int nseg, seg_len;             // time-parallel segments (1 = the whole horizon)
+    T *vseg;                       // [B,nseg,NX] v at the first step of every segment (nseg > 1)
     View<T> A, Bm, c0x, c0u, Qr, Rr;
     const T *xhat, *uhat, *zx, *lx, *zu, *lu;
     const T *K, *Quu, *fac, *Qux;
@@ -30,8 +43,11 @@ struct FfP {
     const int32_t *active;
 };
 
-template <typename T, int NX, int NU, int D>
-__global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
+// D = steps of operands in flight per lane, OCC = wavefronts per SIMD the register budget must allow: the
+// sequential form runs <= 1 wave per SIMD and hides HBM latency with a deep ring; the segmented form has
+// nseg times the waves and trades ring depth for co-residency.
+template <typename T, int NX, int NU, int D, int OCC>
+__global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, MAXTPW = kWave / G;
     // slot record (elements): AB[NX][W] | K[NU][NX] | Qux[NU][NX] | Quu[NU][NU] | fac[NU][NU] | d[W] | v[NX] | qu[NU] | kt[NU] | dump
@@ -51,6 +67,10 @@ __global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
     const bool inbatch = inslot && b < p.B;
     const bool valid = inbatch && (p.active == nullptr || p.active[b] != 0);
     const int N = p.N;
+    // segment of the horizon handled by this workgroup: steps t_hi .. t_lo of the recursion t = N-2 .. 0
+    const int seg = blockIdx.y;
+    const bool last = seg == p.nseg - 1;
+    const int t_lo = seg * p.seg_len, t_hi = last ? N - 2 : t_lo + p.seg_len - 1;
     const int sl = inbatch ? s : 0;                            // idle lanes shadow the block's first trajectory (loads only)
     T *rec = lds + (inslot ? s : TPW) * SLOT;
     const bool xl = i < NX;
@@ -137,129 +157,115 @@ __global__ __launch_bounds__(64) void riccati_ff_kernel(FfP<T> p)
         return hasreg ? c0v + T(2) * sacc : c0v;
     };
 
-    // ---- terminal step: v = cx[N-1], k[N-1] = 0 ------------------------------------------------------
+    // ---- terminal step: v = cx[N-1], k[N-1] = 0 (last segment); the others start from v_in = 0 ----------
+    T vcur;
     {
         Stage term;
         fetch(N - 1, term);
         rec[D_OFF + i] = hasreg ? term.hv - (term.zv - term.lv) : T(0);
         slot_sync();
         const T cterm = reg_grad(term.c0, term.rrow);
-        rec[xl ? V_OFF + i : DUMP_OFF] = cterm;
-        if (valid && !xl) p.k[((int64_t)b * N + N - 1) * NU + iu] = T(0);
+        vcur = last ? cterm : T(0);
+        rec[xl ? V_OFF + i : DUMP_OFF] = vcur;
+        if (valid && !xl && last) p.k[((int64_t)b * N + N - 1) * NU + iu] = T(0);
         slot_sync();
     }
     Stage ring[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) fetch(N - 2 - d > 0 ? N - 2 - d : 0, ring[d]);
+    for (int d = 0; d < D; ++d) fetch(t_hi - d > t_lo ? t_hi - d : t_lo, ring[d]);
 
     T *kout = p.k + (int64_t)(valid ? b : 0) * N * NU + iu;
     const bool kstore = valid && !xl;
 
-#ifdef ISLS_DIAG
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
-#define STAMP(k) { unsigned long long t1_ = __builtin_readcyclecounter(); tacc[k] += t1_ - tprev_; tprev_ = t1_; }
-#else
-#define STAMP(k)
-#endif
-    auto step = [&](int t, Stage &g) {
-#ifdef ISLS_DIAG
-        unsigned long long tprev_ = __builtin_readcyclecounter();
-#endif
-        // (a) stage the operands of step t (unconditional) and publish d_i = xhat_i - (z_i - lambda_i)
+    // Groups of D steps with the ring index a compile-time constant; the last group is padded with dead steps
+    // (t < t_lo: loads clamped, v and k untouched), so the body exists once and every VMEM instruction of the loop
+    // is unconditional (exact vmcnt bookkeeping: D steps of loads really stay in flight).
+    for (int tb = t_hi; tb >= t_lo; tb -= D) {
 #pragma unroll
-        for (int j = 0; j < JA; ++j) rec[dA[j]] = g.ra[j];
+        for (int d = 0; d < D; ++d) {
+            const int t = tb - d;
+            const bool live = t >= t_lo;
+            Stage &g = ring[d];
+            // (a) stage the operands of step t (unconditional) and publish d_i = xhat_i - (z_i - lambda_i)
 #pragma unroll
-        for (int j = 0; j < JB; ++j) rec[dB[j]] = g.rb[j];
+            for (int j = 0; j < JA; ++j) rec[dA[j]] = g.ra[j];
 #pragma unroll
-        for (int j = 0; j < JK; ++j) { rec[dK[j]] = g.rk[j]; rec[dQ[j]] = g.rq[j]; }
+            for (int j = 0; j < JB; ++j) rec[dB[j]] = g.rb[j];
 #pragma unroll
-        for (int j = 0; j < JU; ++j) { rec[dU[j]] = g.ruu[j]; rec[dF[j]] = g.rf[j]; }
-        rec[D_OFF + i] = hasreg ? g.hv - (g.zv - g.lv) : T(0);
-        const T c0_now = g.c0;
-        T row_now[NX];
+            for (int j = 0; j < JK; ++j) { rec[dK[j]] = g.rk[j]; rec[dQ[j]] = g.rq[j]; }
 #pragma unroll
-        for (int j = 0; j < NX; ++j) row_now[j] = g.rrow[j];
-        slot_sync();
-        STAMP(0)
-        fetch(t - D > 0 ? t - D : 0, g);                       // refill this ring entry (clamped, unconditional)
-        STAMP(1)
+            for (int j = 0; j < JU; ++j) { rec[dU[j]] = g.ruu[j]; rec[dF[j]] = g.rf[j]; }
+            rec[D_OFF + i] = hasreg ? g.hv - (g.zv - g.lv) : T(0);
+            const T c0_now = g.c0;
+            T row_now[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) row_now[j] = g.rrow[j];
+            slot_sync();
+            fetch(t - D > t_lo ? t - D : t_lo, g);                 // refill this ring entry (clamped, unconditional)
 
-        // q_i = c_i + ([A B]' v)_i        (isls.py:285-286)
-        const T ci = reg_grad(c0_now, row_now);
-        T sacc = T(0);
+            // q_i = c_i + ([A B]' v)_i        (isls.py:285-286)
+            const T ci = reg_grad(c0_now, row_now);
+            T sacc = T(0);
 #pragma unroll
-        for (int k = 0; k < NX; ++k) sacc += rec[AB_OFF + k * W + i] * rec[V_OFF + k];
-        const T qi = ci + sacc;
-        rec[xl ? DUMP_OFF : QU_OFF + iu] = qi;
-        slot_sync();                                           // (b) qu visible; every lane has read v
-        STAMP(2)
+            for (int k = 0; k < NX; ++k) sacc += rec[AB_OFF + k * W + i] * rec[V_OFF + k];
+            const T qi = ci + sacc;
+            rec[xl ? DUMP_OFF : QU_OFF + iu] = qi;
+            slot_sync();                                           // (b) qu visible; every lane has read v
 
-        // k_t = -Quu^{-1} qu  (every lane), then v_i for x-lanes
-        T qu[NU], kt[NU];
+            // k_t = -Quu^{-1} qu  (every lane), then v_i for x-lanes
+            T qu[NU], kt[NU];
 #pragma unroll
-        for (int r = 0; r < NU; ++r) qu[r] = rec[QU_OFF + r];
-        if (p.mode == ISLS_SOLVE_CHOL) {
-            T U[NU][NU], rd[NU], x[NU];
+            for (int r = 0; r < NU; ++r) qu[r] = rec[QU_OFF + r];
+            if (p.mode == ISLS_SOLVE_CHOL) {
+                T U[NU][NU], rd[NU], x[NU];
 #pragma unroll
-            for (int r = 0; r < NU; ++r) {
+                for (int r = 0; r < NU; ++r) {
 #pragma unroll
-                for (int c = 0; c < NU; ++c) U[r][c] = rec[FAC_OFF + r * NU + c];
-                rd[r] = U[r][r];
+                    for (int c = 0; c < NU; ++c) U[r][c] = rec[FAC_OFF + r * NU + c];
+                    rd[r] = U[r][r];
+                }
+                chol_solve<NU>(U, rd, qu, x);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) kt[r] = -x[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+                    T acc = T(0);
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) acc += rec[FAC_OFF + r * NU + c] * qu[c];
+                    kt[r] = -acc;
+                }
             }
-            chol_solve<NU>(U, rd, qu, x);
+            // v_i = qx_i + (K'qu)_i + (K'Quu k)_i + (Qux'k)_i ; u-lanes evaluate the same expression on their
+            // (clamped) column and throw it away: no divergence
+            const int ic = xl ? i : 0;
+            T t_kqu = T(0), t_kquuk = T(0), t_quxk = T(0);
+            T Kc[NU];
 #pragma unroll
-            for (int r = 0; r < NU; ++r) kt[r] = -x[r];
-        } else {
+            for (int r = 0; r < NU; ++r) { Kc[r] = rec[K_OFF + r * NX + ic]; t_kqu += Kc[r] * qu[r]; }
 #pragma unroll
-            for (int r = 0; r < NU; ++r) {
-                T acc = T(0);
+            for (int c = 0; c < NU; ++c) {
+                T w = T(0);
 #pragma unroll
-                for (int c = 0; c < NU; ++c) acc += rec[FAC_OFF + r * NU + c] * qu[c];
-                kt[r] = -acc;
+                for (int r = 0; r < NU; ++r) w += Kc[r] * rec[QUU_OFF + r * NU + c];
+                t_kquuk += w * kt[c];
             }
+#pragma unroll
+            for (int r = 0; r < NU; ++r) t_quxk += rec[QUX_OFF + r * NX + ic] * kt[r];
+            const T vnew = (p.mode == ISLS_SOLVE_CHOL) ? ((qi + t_kqu) + t_kquuk) + t_quxk      // isls.py:302
+                                                       : ((qi + t_quxk) + t_kqu) + t_kquuk;     // sls.py:200
+            vcur = live ? vnew : vcur;                             // dead (padding) steps leave v alone
+            rec[xl ? V_OFF + i : DUMP_OFF] = vcur;                 // safe: all reads of v happened before (b)
+            // k_t leaves through LDS: every lane holds the same kt[], u-lane r needs entry r -- a per-lane LDS
+            // address does that for free, whereas a select chain over kt[] becomes a scratch-memory array
+#pragma unroll
+            for (int r = 0; r < NU; ++r) rec[KT_OFF + r] = kt[r];
+            slot_sync();
+            const T kv = rec[KT_OFF + iu];
+            if (kstore && live) kout[(int64_t)t * NU] = kv;
         }
-        // v_i = qx_i + (K'qu)_i + (K'Quu k)_i + (Qux'k)_i ; u-lanes evaluate the same expression on their
-        // (clamped) column and throw it away: no divergence
-        const int ic = xl ? i : 0;
-        T t_kqu = T(0), t_kquuk = T(0), t_quxk = T(0);
-        T Kc[NU];
-#pragma unroll
-        for (int r = 0; r < NU; ++r) { Kc[r] = rec[K_OFF + r * NX + ic]; t_kqu += Kc[r] * qu[r]; }
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            T w = T(0);
-#pragma unroll
-            for (int r = 0; r < NU; ++r) w += Kc[r] * rec[QUU_OFF + r * NU + c];
-            t_kquuk += w * kt[c];
-        }
-#pragma unroll
-        for (int r = 0; r < NU; ++r) t_quxk += rec[QUX_OFF + r * NX + ic] * kt[r];
-        const T vnew = (p.mode == ISLS_SOLVE_CHOL) ? ((qi + t_kqu) + t_kquuk) + t_quxk      // isls.py:302
-                                                   : ((qi + t_quxk) + t_kqu) + t_kquuk;     // sls.py:200
-        rec[xl ? V_OFF + i : DUMP_OFF] = vnew;                 // safe: all reads of v happened before (b)
-        // k_t leaves through LDS: every lane holds the same kt[], u-lane r needs entry r -- a per-lane LDS
-        // address does that for free, whereas a select chain over kt[] becomes a scratch-memory array
-#pragma unroll
-        for (int r = 0; r < NU; ++r) rec[KT_OFF + r] = kt[r];
-        slot_sync();
-        const T kv = rec[KT_OFF + iu];
-        if (kstore) kout[(int64_t)t * NU] = kv;
-        STAMP(3)
-    };
-
-    int tb = N - 2;
-    for (; tb - (D - 1) >= 0; tb -= D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) step(tb - d, ring[d]);
     }
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (tb - d >= 0) step(tb - d, ring[d]);
-#ifdef ISLS_DIAG
-    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300))
-        printf("ff diag block %d: stage+wait %llu fetch-issue %llu q %llu solve+v %llu cycles (N=%d)\n", blockIdx.x, tacc[0],
-               tacc[1], tacc[2], tacc[3], N);
-#endif
+    if (seg > 0 && valid && xl) p.vseg[((int64_t)b * p.nseg + seg) * NX + i] = vcur;   // v0 at the segment start
 }
 
 template <typename T>
@@ -282,15 +288,27 @@ int launch_ff(const isls_ff_args &a, hipStream_t s)
     p.zx = (const T *)a.zx; p.lx = (const T *)a.lx; p.zu = (const T *)a.zu; p.lu = (const T *)a.lu;
     p.K = (const T *)a.K; p.Quu = (const T *)a.Quu; p.fac = (const T *)a.fac; p.Qux = (const T *)a.Qux;
     p.k = (T *)a.k; p.active = a.active;
+    const bool segmented = ff_seg_enabled(a.seg) && a.N > 2;
+    p.nseg = segmented ? a.seg.nseg : 1;
+    p.seg_len = segmented ? a.seg.seg_len : (a.N > 1 ? a.N - 1 : 1);
+    p.vseg = segmented ? (T *)a.seg.v : nullptr;
+    if (segmented && (a.seg.nseg > 16 || !a.seg.Psi || !a.seg.v || (int64_t)a.seg.nseg * a.seg.seg_len < a.N - 1 ||
+                      (int64_t)(a.seg.nseg - 1) * a.seg.seg_len >= a.N - 1))
+        return ISLS_ERR_ARG;
 #define CALL(NX_, NU_)                                                                                 \
     {                                                                                                  \
         p.tpw = pick_tpw(a.B, kWave / (NX_ + NU_), "ISLS_FF_TPW");                                     \
         const int grid = (a.B + p.tpw - 1) / p.tpw;                                                    \
-        hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth>), dim3(grid), dim3(64), 0, s, p);  \
+        if (segmented)                                                                                 \
+            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfSegDepth, kFfSegOcc>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
+        else                                                                                           \
+            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth, 1>), dim3(grid), dim3(64), 0, s, p);  \
     }
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
-    return check_launch();
+    const int rc = check_launch();
+    if (rc != ISLS_OK || !segmented) return rc;
+    return launch_ff_stitch<T>(a, s);
 }
 template int launch_ff<double>(const isls_ff_args &, hipStream_t);
 template int launch_ff<float>(const isls_ff_args &, hipStream_t);

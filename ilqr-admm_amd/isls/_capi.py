@@ -40,6 +40,11 @@ class GainArgs(C.Structure):
                 ("status", C.c_void_p), ("active", C.c_void_p)]
 
 
+class FfSeg(C.Structure):
+    """Time-parallel form of the feed-forward pass (isls_ffseg): nseg <= 1 / G NULL = sequential."""
+    _fields_ = [("nseg", C.c_int32), ("seg_len", C.c_int32), ("G", C.c_void_p), ("Psi", C.c_void_p), ("v", C.c_void_p)]
+
+
 class FfArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
                 ("solve_mode", C.c_int32), ("_pad", C.c_int32),
@@ -47,7 +52,15 @@ class FfArgs(C.Structure):
                 ("xhat", C.c_void_p), ("uhat", C.c_void_p),
                 ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
                 ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
-                ("k", C.c_void_p), ("active", C.c_void_p)]
+                ("k", C.c_void_p), ("active", C.c_void_p), ("seg", FfSeg)]
+
+
+class FfPrepareArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("solve_mode", C.c_int32), ("_pad", C.c_int32),
+                ("A", View), ("Bm", View),
+                ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
+                ("active", C.c_void_p), ("seg", FfSeg)]
 
 
 class RolloutArgs(C.Structure):
@@ -109,9 +122,9 @@ class OuterArgs(C.Structure):
 
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
-            ("riccati_gain", "riccati_ff", "rollout_ls", "admm_update", "expand_quadratic", "linearize",
+            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
-           ["isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_read_ms"]
+           ["isls_ff_segments", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_read_ms"]
 
 
 class IslsError(RuntimeError):
@@ -249,9 +262,11 @@ class Kernels:
 
     @staticmethod
     def ff_args(A, Bm, c0x, c0u, K, Quu, fac, Qux, k, Qr=None, Rr=None, xhat=None, uhat=None,
-                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None):
+                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None, seg=None):
         B, N, m, n = K.shape
         a = FfArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode)
+        if seg is not None:
+            a.seg = seg
         a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
         a.c0x, a.c0u = make_view(c0x, B, N, (n,), "c0x"), make_view(c0u, B, N, (m,), "c0u")
         a.Qr, a.Rr = make_view(Qr, B, N, (n, n), "Qr"), make_view(Rr, B, N, (m, m), "Rr")
@@ -265,6 +280,24 @@ class Kernels:
         a.K, a.Quu = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(Quu, (B, N, m, m), "Quu"))
         a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
         a.k = _ptr(_dense(k, (B, N, m), "k"))
+        a.active = _ptr(active)
+        return a
+
+    @staticmethod
+    def ff_seg(G, Psi, v, seg_len):
+        """isls_ffseg over caller-owned buffers G[B,N,m,n], Psi[B,nseg,n,n], v[B,nseg,n]."""
+        B, N, m, n = G.shape
+        nseg = int(Psi.shape[1])
+        _dense(G, (B, N, m, n), "seg.G"), _dense(Psi, (B, nseg, n, n), "seg.Psi"), _dense(v, (B, nseg, n), "seg.v")
+        return FfSeg(nseg=nseg, seg_len=int(seg_len), G=_ptr(G), Psi=_ptr(Psi), v=_ptr(v))
+
+    @staticmethod
+    def ff_prepare_args(A, Bm, K, Quu, fac, Qux, seg, solve_mode=SOLVE_CHOL, active=None):
+        B, N, m, n = K.shape
+        a = FfPrepareArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode, seg=seg)
+        a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
+        a.K, a.Quu = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(Quu, (B, N, m, m), "Quu"))
+        a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
         a.active = _ptr(active)
         return a
 
@@ -334,6 +367,18 @@ class Kernels:
     def riccati_ff(self, *args, stream=None, **kw):
         a = self.ff_args(*args, **kw)
         return self._call("riccati_ff", _sfx(args[4]), a, stream)
+
+    def riccati_ff_prepare(self, *args, stream=None, **kw):
+        a = self.ff_prepare_args(*args, **kw)
+        return self._call("riccati_ff_prepare", _sfx(args[2]), a, stream)
+
+    def ff_segments(self, N, nseg_requested):
+        """(nseg, seg_len) the library uses for a horizon of N steps."""
+        fn = self.lib.isls_ff_segments
+        fn.restype = C.c_int32
+        seg_len = C.c_int32(0)
+        nseg = int(fn(C.c_int32(int(N)), C.c_int32(int(nseg_requested)), C.byref(seg_len)))
+        return nseg, int(seg_len.value)
 
     def rollout_ls(self, *args, stream=None, **kw):
         a = self.rollout_args(*args, **kw)

@@ -12,6 +12,7 @@ contiguous stream (A: N*n*n, K: N*m*n, x: N*n ... elements) that a wavefront slo
 bounds, rho weights) are passed with zero batch/time strides and stay cache-resident.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -179,10 +180,11 @@ class Engine:
                                Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active,
                                stream=_stream_ptr())
 
-    def feedforward(self, active=None):
+    def feedforward(self, active=None, seg=None):
         self.kern.riccati_ff(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                              Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx,
-                             zu=self.zu, lu=self.lu, solve_mode=self.solve_mode, active=active, stream=_stream_ptr())
+                             zu=self.zu, lu=self.lu, solve_mode=self.solve_mode, active=active, seg=seg,
+                             stream=_stream_ptr())
 
     def rollout(self, L, flags=0, cost_all=None, active=None):
         self.kern.rollout_ls(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
@@ -197,15 +199,35 @@ class Engine:
                               tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=active,
                               iters=self.admm_iters, stream=_stream_ptr())
 
+    # ---- time-parallel feed-forward pass (isls_ffseg): operators from the gain pass, reused by J ADMM iterations
+    def ff_seg(self, nseg_requested=None):
+        """Segment descriptor over engine-owned buffers, or None for the sequential recursion."""
+        if nseg_requested is None:
+            # measured on MI355X (DESIGN.md 5): below ~4k trajectories the pass is bound by the N dependent steps and
+            # more segments keep paying; above, it is bound by HBM throughput and 3 segments (<= 2 co-resident
+            # wavefronts per SIMD, no register spills) are the sweet spot
+            nseg_requested = int(os.environ.get("ISLS_FF_NSEG", "3" if self.B >= 4096 else "4"))
+        nseg, seg_len = self.kern.ff_segments(self.N, nseg_requested)
+        if nseg < 2:
+            return None
+        if getattr(self, "_seg_bufs", None) is None or self._seg_bufs[1].shape[1] != nseg:
+            z = lambda *shape: torch.zeros(*shape, dtype=self.dtype, device=self.device)
+            self._seg_bufs = (z(self.B, self.N, self.m, self.n), z(self.B, nseg, self.n, self.n), z(self.B, nseg, self.n))
+        return capi.Kernels.ff_seg(*self._seg_bufs, seg_len)
+
+    def feedforward_prepare(self, seg, active=None):
+        self.kern.riccati_ff_prepare(self.A, self.Bm, self.K, self.Quu, self.fac, self.Qux, seg,
+                                     solve_mode=self.solve_mode, active=active, stream=_stream_ptr())
+
     # ---- one outer iteration, enqueued by the C driver in one call --------------------------------------------
-    def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None):
+    def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None, ff_nseg=None):
         """Marshal the argument block of isls_ilqr_admm_outer once; it stays valid while buffers are not re-allocated."""
         K = capi.Kernels
         gain = K.gain_args(self.A, self.Bm, self.Cxx, self.Cuu, self.K, self.Quu, self.fac, self.Qux, Cux=self.Cux,
                            solve_mode=self.solve_mode, status=self.status, active=self.admm_active)
         ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                        Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
-                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active)
+                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=self.ff_seg(ff_nseg))
         ro = K.rollout_args(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
                             self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,
                             cost_new=self.cost_new, wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx, zu=self.zu,

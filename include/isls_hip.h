@@ -111,7 +111,28 @@ int isls_riccati_gain_f32(const isls_gain_args *a, void *stream);
  * (the ADMM regulariser of isls/sls.py:132-137 and of O2).  xhat/uhat NULL -> 0 (absolute
  * coordinates, SLS path).  Qr.p / Rr.p NULL -> that term (and zx,lx / zu,lu) is unused.
  * Output k[B,N,m] (k[N-1]=0).
+ *
+ * Time-parallel form (optional, `seg`).  The recursion is affine in v: v_t = Phi_t v_{t+1} + g_t and
+ * k_t = Gamma_t v_{t+1} + h_t, where Phi_t, Gamma_t depend only on A, B and the gain-pass outputs.  With
+ * the N-1 steps cut into nseg segments of seg_len steps, every segment recurses concurrently from
+ * v_in = 0 (the last one from the terminal gradient), the true segment inputs follow from nseg-2 small
+ * mat-vecs with the segment transfer matrices Psi_s = Phi_{t0} ... Phi_{t1-1}, and k_t += G_t v_in(seg(t))
+ * with G_t = Gamma_t Phi_{t+1} ... Phi_{t1-1}.  G and Psi are produced once per gain pass by
+ * isls_riccati_ff_prepare_* and reused by every ADMM iteration; the result equals the sequential
+ * recursion up to rounding (a different association of the same sums).
  * ------------------------------------------------------------------------------------------- */
+typedef struct isls_ffseg {
+    int32_t nseg;     /* <= 1 or G == NULL: sequential recursion over the whole horizon            */
+    int32_t seg_len;  /* steps per segment; (nseg, seg_len) as returned by isls_ff_segments()       */
+    void *G;          /* [B,N,m,n]     k_t correction operators          (prepare -> ff)           */
+    void *Psi;        /* [B,nseg,n,n]  segment transfer matrices         (prepare -> ff)           */
+    void *v;          /* [B,nseg,n]    scratch of the ff pass (segment-start values of v)          */
+} isls_ffseg;
+
+/* Effective segmentation of a horizon of N steps for a requested segment count: returns nseg (>= 1)
+ * and stores the segment length; every segment is non-empty. */
+int32_t isls_ff_segments(int32_t N, int32_t nseg_requested, int32_t *seg_len);
+
 typedef struct isls_ff_args {
     int32_t B, N, n, m;
     int32_t solve_mode;
@@ -126,10 +147,26 @@ typedef struct isls_ff_args {
     const void *K, *Quu, *fac, *Qux;
     void *k;
     const int32_t *active;
+    isls_ffseg seg;                 /* zero-initialised => sequential */
 } isls_ff_args;
 
 int isls_riccati_ff_f64(const isls_ff_args *a, void *stream);
 int isls_riccati_ff_f32(const isls_ff_args *a, void *stream);
+
+/* Operators of the time-parallel feed-forward pass (see isls_ffseg): run after the gain pass whenever
+ * A, B, K, Quu, fac or Qux changed.  Writes seg.G for t < (nseg-1)*seg_len and seg.Psi for 1 <= s <= nseg-2. */
+typedef struct isls_ff_prepare_args {
+    int32_t B, N, n, m;
+    int32_t solve_mode;
+    int32_t _pad;
+    isls_view A, Bm;
+    const void *K, *Quu, *fac, *Qux;
+    const int32_t *active;
+    isls_ffseg seg;
+} isls_ff_prepare_args;
+
+int isls_riccati_ff_prepare_f64(const isls_ff_prepare_args *a, void *stream);
+int isls_riccati_ff_prepare_f32(const isls_ff_prepare_args *a, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Forward line-search rollout + cost + arg-min + winner trajectory.
@@ -289,7 +326,8 @@ typedef struct isls_outer_args {
     isls_rollout_args ro;
     isls_admm_args admm;
     int32_t J;
-    int32_t skip_gain;          /* reuse the cached factors (is_dynamics_linear && is_cost_quadratic) */
+    int32_t skip_gain;          /* reuse the cached factors (is_dynamics_linear && is_cost_quadratic);
+                                 * when the gain pass runs and ff.seg is set, the ff operators are prepared too */
     void *log;
     const int32_t *outer_active;
 } isls_outer_args;
@@ -300,7 +338,7 @@ int isls_ilqr_admm_outer_f32(const isls_outer_args *a, void *stream);
 int isls_version(void);
 const char *isls_error_string(int code);
 /* name + duration bookkeeping used by bench.py: records hipEvents around the launches of one
- * kernel family on `stream`. kind: 0 gain, 1 ff, 2 rollout, 3 admm.  Returns ms of the last
+ * kernel family on `stream`. kind: 0 gain, 1 ff, 2 rollout, 3 admm, 4 ff_prepare.  Returns ms of the last
  * completed timed launch set, or <0 if timing is disabled. */
 int isls_timing_enable(int on);
 double isls_timing_read_ms(int kind, int *count);

@@ -7,8 +7,11 @@ from isls import _capi as capi
 
 
 class DualKernels:
-    def __init__(self, oracle, hip, tol=1e-10, int_exact=True, verbose=False):
+    def __init__(self, oracle, hip, tol=1e-10, int_exact=True, verbose=False, ff_nseg=1):
         self.oracle, self.hip, self.tol, self.int_exact, self.verbose = oracle, hip, tol, int_exact, verbose
+        # > 1: the HIP side runs the feed-forward pass in its time-parallel form (isls_ffseg: prepare + segmented
+        # recursion + stitch) while the oracle keeps the reference's sequential recursion
+        self.ff_nseg = ff_nseg
         self.max_err = {}
         self.calls = 0
 
@@ -42,6 +45,8 @@ class DualKernels:
         dargs = [self._to_dev(a) for a in args]
         dkw = {k: self._to_dev(v) for k, v in kw.items()}
         getattr(self.oracle, name)(*args, **kw)
+        if name == "riccati_ff" and self.ff_nseg > 1:
+            dkw = dict(dkw, seg=self._prepare_segments(dargs, dkw))
         getattr(self.hip, name)(*dargs, **dkw)
         torch.cuda.synchronize()
         self.calls += 1
@@ -51,6 +56,20 @@ class DualKernels:
         for k in kw:
             if isinstance(kw[k], np.ndarray):
                 self._compare(name, k, kw[k], dkw[k])
+
+    def _prepare_segments(self, dargs, dkw):
+        """Fresh NaN-filled operator buffers + isls_riccati_ff_prepare on the device operands of an ff call."""
+        A, Bm, _, _, K, Quu, fac, Qux = dargs[:8]
+        B, N, m, n = K.shape
+        nseg, seg_len = self.hip.ff_segments(N, self.ff_nseg)
+        if nseg < 2:
+            return None
+        nan = lambda *shape: torch.full(shape, float("nan"), dtype=K.dtype, device=K.device)   # noqa: E731
+        self._seg_bufs = (nan(B, N, m, n), nan(B, nseg, n, n), nan(B, nseg, n))
+        seg = capi.Kernels.ff_seg(*self._seg_bufs, seg_len)
+        self.hip.riccati_ff_prepare(A, Bm, K, Quu, fac, Qux, seg, solve_mode=dkw.get("solve_mode", capi.SOLVE_CHOL),
+                                    active=dkw.get("active"))
+        return seg
 
     def __getattr__(self, name):
         if name in ("riccati_gain", "riccati_ff", "rollout_ls", "admm_update", "expand_quadratic", "linearize", "accept_step"):

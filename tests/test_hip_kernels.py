@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def dual(oracle):
     from dual import DualKernels, hip_kernels
-    return lambda tol=1e-10: DualKernels(oracle, hip_kernels(), tol=tol)
+    return lambda tol=1e-10, ff_nseg=1: DualKernels(oracle, hip_kernels(), tol=tol, ff_nseg=ff_nseg)
 
 
 def _report(dk):
@@ -24,11 +24,11 @@ def _report(dk):
     print("calls", dk.calls, "worst:", ", ".join(f"{k}={v:.1e}" for k, v in worst))
 
 
-@pytest.mark.parametrize("B", [1, 7, 23])
-def test_di3d_all_kernels(dual, B):
+@pytest.mark.parametrize("B,ff_nseg", [(1, 1), (7, 1), (23, 1), (7, 4), (23, 5)])
+def test_di3d_all_kernels(dual, B, ff_nseg):
     cfg = P.config2(batch=32, N=100, seed=1)
     pa = problem_arrays(cfg, range(B))
-    dk = dual()
+    dk = dual(ff_nseg=ff_nseg)
     d = OracleDriver(dk, pa, rho_u=cfg["rho_u"], relax=cfg["relax"])
     d.run(2, 20, 3, 0.0)
     # state box + relaxation + natural stop (freezing of converged trajectories)
@@ -105,21 +105,23 @@ def test_double_integrator_model_equals_dense_lti(oracle):
     assert np.array_equal(A.cpu().numpy(), d.A) and np.array_equal(Bm.cpu().numpy(), d.Bm)
 
 
-def test_arm_all_kernels(dual, golden):
+@pytest.mark.parametrize("ff_nseg", [1, 4])
+def test_arm_all_kernels(dual, golden, ff_nseg):
     g = golden("g4_arm3r.npz")
     sens = max(float(v) for v in g["o2_sens"])
     cfg = P.config3(batch=16, N=100, seed=0)
     pa = problem_arrays(cfg, range(7))
-    dk = dual(tol=max(1e-10, 10 * sens))
+    dk = dual(tol=max(1e-10, 10 * sens), ff_nseg=ff_nseg)
     d = OracleDriver(dk, pa, rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
     d.run(3, cfg["max_line_search"], cfg["max_admm_iter"], 0.0)
     _report(dk)
 
 
-def test_car_all_kernels(dual):
+@pytest.mark.parametrize("ff_nseg", [1, 8])
+def test_car_all_kernels(dual, ff_nseg):
     cfg = P.config4(batch=16, N=200, seed=0)
     pa = problem_arrays(cfg, range(13))
-    dk = dual()
+    dk = dual(ff_nseg=ff_nseg)
     d = OracleDriver(dk, pa, rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
     d.run(3, 20, cfg["max_admm_iter"], 0.0)
     _report(dk)
@@ -149,6 +151,29 @@ def test_di1d_sls_inverse_mode(dual):
     x0 = rng.standard_normal((B, n)) * 0.1
     dk.rollout_ls(capi.MODEL_LTI, par, K, k, z(B, N, n), z(B, N, m), np.ones(1), c["Qs"], c["zs"], c["seq"],
                   c["u_std"], xx, xu, x0=x0, flags=capi.RO_ABSOLUTE, cost_new=z(B), best=np.zeros(B, dtype=np.int32))
+    _report(dk)
+
+
+@pytest.mark.parametrize("N,nseg", [(2, 4), (3, 2), (4, 3), (10, 4), (33, 16), (100, 3), (100, 7)])
+def test_time_parallel_feedforward(dual, N, nseg):
+    """isls_ffseg: segmented recursion + stitch against the oracle's sequential feed-forward pass, over horizon /
+    segment-count pairs with ragged last segments, frozen trajectories and both solve modes."""
+    cfg = P.config2(batch=16, N=N, seed=5)
+    pa = problem_arrays(cfg, range(11))
+    for mode in (capi.SOLVE_CHOL, capi.SOLVE_INV):
+        dk = dual(ff_nseg=nseg)
+        d = OracleDriver(dk, pa, rho_x=0.05, rho_u=cfg["rho_u"], project_x=True)
+        d.linearize_expand()
+        d.admm_active[[2, 5]] = 0
+        rng = np.random.default_rng(N)
+        for arr in (d.zx, d.zu, d.lx, d.lu):
+            arr[:] = 0.3 * rng.standard_normal(arr.shape)
+        dk.riccati_gain(d.A, d.Bm, d.Cxx, d.Cuu, d.K, d.Quu, d.fac, d.Qux, solve_mode=mode, status=d.status,
+                        active=d.admm_active)
+        d.k[:] = 7.0                                            # frozen trajectories must keep this
+        dk.riccati_ff(d.A, d.Bm, d.c0x, d.c0u, d.K, d.Quu, d.fac, d.Qux, d.k, Qr=d.Qr, Rr=d.Rr, xhat=d.xhat,
+                      uhat=d.uhat, zx=d.zx, lx=d.lx, zu=d.zu, lu=d.lu, solve_mode=mode, active=d.admm_active)
+        assert np.all(d.k[[2, 5]] == 7.0)
     _report(dk)
 
 

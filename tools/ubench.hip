@@ -4,6 +4,14 @@
 #include <cstdio>
 #include <vector>
 
+template <int K> __device__ __forceinline__ double rowbcast(double v)   // lane K of each 16-lane row -> whole row
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k(double *out, int iters, unsigned long long *cyc)
 {
@@ -24,6 +32,32 @@ __global__ __launch_bounds__(64) void k(double *out, int iters, unsigned long lo
             const double *p = lds + ((it & 7) * 8);
             a0 = __builtin_fma(a0, p[0], c); a1 = __builtin_fma(a1, p[1], c); a2 = __builtin_fma(a2, p[2], c); a3 = __builtin_fma(a3, p[3], c);
             a4 = __builtin_fma(a4, p[4], c); a5 = __builtin_fma(a5, p[5], c); a6 = __builtin_fma(a6, p[6], c); a7 = __builtin_fma(a7, p[7], c);
+        } else if (MODE == 4) {  // 6x6 mat-vec recursion, x exchanged inside each 16-lane row by DPP row_newbcast
+            double acc = c;
+            acc = __builtin_fma(a1, rowbcast<0>(a0), acc); acc = __builtin_fma(a2, rowbcast<1>(a0), acc);
+            acc = __builtin_fma(a3, rowbcast<2>(a0), acc); acc = __builtin_fma(a4, rowbcast<3>(a0), acc);
+            acc = __builtin_fma(a5, rowbcast<4>(a0), acc); acc = __builtin_fma(a6, rowbcast<5>(a0), acc);
+            a0 = acc * 1e-3;
+        } else if (MODE == 5) {  // the same recursion with the exchange through LDS (write, wave fence, 6 broadcast reads)
+            lds[threadIdx.x] = a0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double *p = lds + (threadIdx.x & 48);
+            double acc = c;
+            acc = __builtin_fma(a1, p[0], acc); acc = __builtin_fma(a2, p[1], acc); acc = __builtin_fma(a3, p[2], acc);
+            acc = __builtin_fma(a4, p[3], acc); acc = __builtin_fma(a5, p[4], acc); acc = __builtin_fma(a6, p[5], acc);
+            a0 = acc * 1e-3;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else if (MODE == 6) {  // 8 independent 32-bit integer VALU ops
+            int *q = reinterpret_cast<int *>(&a0);
+            (void)q;
+            unsigned u0 = __double2loint(a0), u1 = __double2loint(a1), u2 = __double2loint(a2), u3 = __double2loint(a3);
+            unsigned u4 = __double2hiint(a0), u5 = __double2hiint(a1), u6 = __double2hiint(a2), u7 = __double2hiint(a3);
+            u0 = u0 * 3u + it; u1 = u1 * 5u + it; u2 = u2 * 7u + it; u3 = u3 * 9u + it;
+            u4 = (u4 ^ it) + 1u; u5 = (u5 ^ it) + 3u; u6 = (u6 ^ it) + 5u; u7 = (u7 ^ it) + 7u;
+            a0 = __hiloint2double(u4, u0); a1 = __hiloint2double(u5, u1); a2 = __hiloint2double(u6, u2); a3 = __hiloint2double(u7, u3);
         } else if (MODE == 3) {  // fp32: 8 independent FMAs
             float f0 = (float)a0, f1 = (float)a1;
             (void)f0; (void)f1;
@@ -60,6 +94,9 @@ int main()
         run<0>("f64 8 indep FMA", blocks, it);
         run<1>("f64 8 dependent FMA", blocks, it);
         run<2>("f64 8 FMA + LDS bcast", blocks, it);
+        run<4>("matvec6 chain, DPP", blocks, it);
+        run<5>("matvec6 chain, LDS", blocks, it);
+        run<6>("int32 8 ops(16 instr)", blocks, it);
     }
     return 0;
 }
