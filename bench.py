@@ -216,7 +216,7 @@ def cpu_baseline(cfg, args, B, N, n, m, J, L):
 
     kern, lib = orc.load()
     cores = orc.set_threads(lib, host_cores())
-    sample = args.cpu_sample or min(B, 1024)
+    sample = args.cpu_sample or min(B, 4096)
     scfg = P.config2(batch=sample, N=N, seed=0)
     pa = problem_arrays(scfg, range(sample))
     d = OracleDriver(kern, pa, rho_u=scfg["rho_u"], relax=scfg["relax"])
@@ -226,7 +226,7 @@ def cpu_baseline(cfg, args, B, N, n, m, J, L):
         d.run_c(L, J)                                         # linearise+expand, C driver, accept
         reps += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 20:
+        if el > 12.0 or reps >= 2000:                         # ~12 s of CPU work on all host cores
             break
     traj_it_per_s = sample * reps / el
     return {"value": traj_it_per_s / B, "unit": "iterations/s", "cores": cores, "kind": "port",

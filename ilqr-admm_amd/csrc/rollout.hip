@@ -191,24 +191,6 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
         stp[j] = has_a[j] ? st : 0;
         dst[j] = (c < GL && e < REC) ? e : O_DUMP;
     });
-    struct Stage {
-        T a[JM], b[JM];
-    };
-    auto fetch = [&](int t, Stage &g) {                       // raw, unconditional loads (no use of the results here)
-        static_for<JM>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            const int64_t o = (int64_t)t * stp[j];
-            g.a[j] = pa[j][o];
-            g.b[j] = pb[j][o];
-        });
-    };
-    auto put = [&](T *rec, const Stage &g) {                  // unconditional ds_writes (dump word for surplus)
-        static_for<JM>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            rec[dst[j]] = has_a[j] ? (has_b[j] ? g.a[j] - g.b[j] : g.a[j]) : T(0);   // z - lambda
-        });
-    };
-
     Model<T, NX, NU, MODEL> model;
     model.load(p.par + (int64_t)bb * p.par_sb, mdl, c < GL ? c : 0, GL);
     slot_sync();
@@ -237,12 +219,6 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
         qm2 = __ballot(lane + 128 < N && qnzp[lane + 128 < N ? lane + 128 : 0] != 0);
         qm3 = __ballot(lane + 192 < N && qnzp[lane + 192 < N ? lane + 192 : 0] != 0);
     }
-    auto q_nonzero_at = [&](int t) -> bool {
-        if (!use_mask) return qnzp == nullptr || qnzp[t] != 0;
-        const int w = t >> 6;
-        const unsigned long long m = w == 0 ? qm0 : (w == 1 ? qm1 : (w == 2 ? qm2 : qm3));
-        return ((m >> (t & 63)) & 1ull) != 0;
-    };
     // ================================ SEARCH ==========================================================
     const T alpha = absolute ? T(1) : p.alphas[c < L ? c : 0];
     T x[NX];
@@ -250,73 +226,97 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
     for (int j = 0; j < NX; ++j) x[j] = x0p ? x0p[j] : T(0);
     T cst = T(0), cu = T(0), ag = T(0);
     {
-        Stage ring[D];
+        // Ring of record elements D steps ahead (raw, unconditional loads; masks are applied when staging).  The
+        // horizon is walked in groups of D steps with the ring index a compile-time constant; the last group is
+        // padded with dead steps (t >= N: loads clamped, nothing accumulated or stored), so the body exists once,
+        // stays free of closures (a step lambda keeps its captures in scratch memory, and a scratch access per
+        // step drains the ring with s_waitcnt vmcnt(0)) and every VMEM instruction of the loop is unconditional.
+        T ra[D][JM], rb[D][JM];
 #pragma unroll
-        for (int d = 0; d < D; ++d) fetch(d < N ? d : N - 1, ring[d]);
+        for (int d = 0; d < D; ++d) {
+            const int64_t tt = d < N ? d : N - 1;
+#pragma unroll
+            for (int j = 0; j < JM; ++j) { ra[d][j] = pa[j][tt * stp[j]]; rb[d][j] = pb[j][tt * stp[j]]; }
+            __builtin_amdgcn_sched_barrier(0);                  // keep the issue order = consumption order (vmcnt is in-order)
+        }
         T *ckc = ck + (c < L ? c : L) * NSEG * NX;             // this candidate's checkpoints (row L = dump)
         int next_ck = 0, seg = 0;
-        auto step = [&](int t, Stage &g) {
-            RSTAMP_BEGIN
-            T *rec = recs + (t & 1) * RECP;
-            put(rec, g);
-            slot_sync();                                      // record(t) visible to the slot
-            RSTAMP(0)
-            fetch(t + D < N ? t + D : N - 1, g);               // refill this ring entry (clamped, unconditional)
-            RSTAMP(1)
-            if (t == next_ck) {                                // uniform: state of every candidate at a segment start
+        for (int tb = 0; tb < N; tb += D) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) ckc[seg * NX + j] = x[j];
-                ++seg;
-                next_ck += S;
-            }
-            // u = (x - xhat) K' + alpha k + uhat            (isls.py:328-329)
-            T u[NU];
+            for (int d = 0; d < D; ++d) {
+                const int t = tb + d;
+                const bool live = t < N;
+                RSTAMP_BEGIN
+                T *rec = recs + (t & 1) * RECP;
 #pragma unroll
-            for (int r = 0; r < NU; ++r) {
-                T acc = T(0);
+                for (int j = 0; j < JM; ++j)                   // unconditional ds_writes (dump word for surplus); z - lambda
+                    rec[dst[j]] = has_a[j] ? (has_b[j] ? ra[d][j] - rb[d][j] : ra[d][j]) : T(0);
+                slot_sync();                                   // record(t) visible to the slot
+                RSTAMP(0)
+                {
+                    const int64_t tn = t + D < N ? t + D : N - 1;   // refill this ring entry (clamped, unconditional)
 #pragma unroll
-                for (int j = 0; j < NX; ++j) acc += (x[j] - rec[O_XH + j]) * rec[O_K + r * NX + j];
-                u[r] = (acc + alpha * rec[O_KK + r]) + rec[O_UH + r];
-            }
-            RSTAMP(2)
-            if (q_nonzero_at(t)) {                             // (x-z)'Q(x-z), skipped where Q_t == 0
-                const T *Q = Qtab + (int64_t)seqp[t] * NX * NX, *z = ztab + (int64_t)seqp[t] * NX;
-                T d[NX];
+                    for (int j = 0; j < JM; ++j) { ra[d][j] = pa[j][tn * stp[j]]; rb[d][j] = pb[j][tn * stp[j]]; }
+                }
+                RSTAMP(1)
+                if (t == next_ck && live) {                    // uniform: state of every candidate at a segment start
 #pragma unroll
-                for (int j = 0; j < NX; ++j) d[j] = x[j] - z[j];
+                    for (int j = 0; j < NX; ++j) ckc[seg * NX + j] = x[j];
+                    ++seg;
+                    next_ck += S;
+                }
+                // u = (x - xhat) K' + alpha k + uhat            (isls.py:328-329)
+                T u[NU];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
+                for (int r = 0; r < NU; ++r) {
                     T acc = T(0);
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) acc += Q[i * NX + j] * d[j];
-                    cst += d[i] * acc;
+                    for (int j = 0; j < NX; ++j) acc += (x[j] - rec[O_XH + j]) * rec[O_K + r * NX + j];
+                    u[r] = (acc + alpha * rec[O_KK + r]) + rec[O_UH + r];
                 }
+                RSTAMP(2)
+                T cst1 = cst, cu1 = cu, ag1 = ag;
+                bool nz = live;                                // (x-z)'Q(x-z), skipped where Q_t == 0 (uniform test)
+                if (use_mask) {
+                    const int w = t >> 6;
+                    const unsigned long long mm = w == 0 ? qm0 : (w == 1 ? qm1 : (w == 2 ? qm2 : qm3));
+                    nz = live && ((mm >> (t & 63)) & 1ull) != 0;
+                }
+                if (nz) {
+                    const int sq = seqp[t];
+                    const T *Q = Qtab + (int64_t)sq * NX * NX, *z = ztab + (int64_t)sq * NX;
+                    T dq[NX];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) dq[j] = x[j] - z[j];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) acc += Q[i * NX + j] * dq[j];
+                        cst1 += dq[i] * acc;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < NU; ++r) cu1 += u[r] * (ustd * u[r]);
+                if (has_wq) {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) { const T df = x[j] - rec[O_RX + j]; ag1 += (df * df) * rec[O_WQ + j]; }
+                }
+                if (has_wr) {
+#pragma unroll
+                    for (int r = 0; r < NU; ++r) { const T df = u[r] - rec[O_RU + r]; ag1 += (df * df) * rec[O_WR + r]; }
+                }
+                cst = live ? cst1 : cst;                       // dead (padding) steps leave the sums alone
+                cu = live ? cu1 : cu;
+                ag = live ? ag1 : ag;
+                RSTAMP(3)
+                T xn[NX];
+                model.step(x, u, xn);                          // x = f(x, u)   (isls.py:332)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) x[j] = xn[j];
+                RSTAMP(4)
             }
-#pragma unroll
-            for (int r = 0; r < NU; ++r) cu += u[r] * (ustd * u[r]);
-            if (has_wq) {
-#pragma unroll
-                for (int j = 0; j < NX; ++j) { const T d = x[j] - rec[O_RX + j]; ag += (d * d) * rec[O_WQ + j]; }
-            }
-            if (has_wr) {
-#pragma unroll
-                for (int r = 0; r < NU; ++r) { const T d = u[r] - rec[O_RU + r]; ag += (d * d) * rec[O_WR + r]; }
-            }
-            RSTAMP(3)
-            T xn[NX];
-            model.step(x, u, xn);                              // x = f(x, u)   (isls.py:332)
-#pragma unroll
-            for (int j = 0; j < NX; ++j) x[j] = xn[j];
-            RSTAMP(4)
-        };
-        int tb = 0;
-        for (; tb + D <= N; tb += D) {                         // full groups: branch-free, exact vmcnt bookkeeping
-#pragma unroll
-            for (int d = 0; d < D; ++d) step(tb + d, ring[d]);
         }
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (tb + d < N) step(tb + d, ring[d]);
     }
 
 #ifdef ISLS_DIAG
