@@ -29,6 +29,7 @@ for p in (os.path.join(ROOT, "ilqr-admm_amd"), ROOT, os.path.join(ROOT, "tests")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+EVENT_PERIOD = 4               # kernel-family durations are sampled on every 4th timed step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 KIND_NAMES = ["riccati_gain_kernel", "riccati_ff_kernel", "rollout_kernel", "admm_update_kernel", "ff_prepare_kernel"]
 # kernels behind each timed family (isls_timing kind): the time-parallel feed-forward pass is two launches
@@ -136,7 +137,10 @@ def main():
     torch.cuda.synchronize()
     lib.isls_timing_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # per-launch HIP events on every EVENT_PERIOD-th step of the timed region: an event pair per launch costs a
+        # few microseconds of queue bubbles (measured: 2.03 ms per step with events on every step, 1.89 without)
+        lib.isls_timing_pause(0 if i % EVENT_PERIOD == 0 else 1)
         step()
     if dist is not None:
         dist.barrier()
@@ -148,18 +152,51 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    red_host = red.cpu().numpy()
+
+    # ---- the same workload with A,B shared over batch and time (stride-0 views; SURVEY 8(d): "report both") ----
+    lti_it_per_s = None
+    if not args.lti:
+        eng.A = torch.as_tensor(cfg["A"], device=dev).reshape(1, 1, n, n)
+        eng.Bm = torch.as_tensor(cfg["B"], device=dev).reshape(1, 1, n, m)
+        eng.build_outer(L, J, tol_abs=0.0, tol_rel=0.0)
+
+        def step_lti():
+            eng.expand()
+            eng.run_outer()
+            eng.accept_x_step()
+            eng.reduce()
+            allreduce_convergence(eng.out5, rank, world, buf=red)
+
+        step_lti()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_lti()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dl = time.perf_counter() - t1
+        if dist is not None:
+            tl = torch.tensor([dl], dtype=torch.float64, device=dev)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            dl = float(tl.item())
+        lti_it_per_s = world * args.steps / dl
+
     # ---- per-kernel-family durations from the HIP events recorded on the launch stream ------------
     fam = []
     for kind in range(5):
         cnt = ctypes.c_int(0)
         ms = lib.isls_timing_read_ms(kind, ctypes.byref(cnt))
         fam.append((ms, cnt.value))
-    red_host = red.cpu().numpy()
 
     if rank == 0:
         it_per_s = world * args.steps / dt
         w = 8
         abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti)
+        sampled = len(range(0, args.steps, EVENT_PERIOD))
         dom = int(np.argmax([ms for ms, _ in fam]))
         default_workload = (B, N, J, L) == (4096, 100, 5, 20) and not args.lti
         avg_ms = fam[dom][0] / max(1, fam[dom][1])
@@ -173,7 +210,7 @@ def main():
             "config": {"workload": "config2: 3-D double integrator iLQR-ADMM (DP form), box constraint on u",
                        "batch_per_gpu": B, "horizon": N, "x_dim": n, "u_dim": m, "admm_iters_J": J,
                        "line_search_L": L, "layout": "LTI stride-0 A,B" if args.lti else "time-varying A,B per trajectory",
-                       "early_exit": False,
+                       "early_exit": False, "lti_stride0_layout_iterations_per_s": lti_it_per_s,
                        "ff_time_parallel_segments": max(1, int(eng._outer_args.ff.seg.nseg)), "trajectory_iterations_per_s": it_per_s * B,
                        "admm_iterations_per_s": it_per_s * J},
             "roofline": {"bound": "hbm", "kernel": KIND_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -182,8 +219,9 @@ def main():
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": abytes[dom] * B,
                          "iteration_algorithmic_bytes": it_bytes,
                          "iteration_frac": it_bytes * (it_per_s / world) / 1e9 / HBM_PEAK_GBS},
-            "kernels_ms_per_step": {KIND_NAMES[k]: fam[k][0] / args.steps for k in range(5)},
-            "launches_per_step": {KIND_NAMES[k]: fam[k][1] / args.steps for k in range(5)},
+            "kernels_ms_per_step": {KIND_NAMES[k]: fam[k][0] / sampled for k in range(5)},
+            "launches_per_step": {KIND_NAMES[k]: fam[k][1] / sampled for k in range(5)},
+            "event_sampled_steps": sampled,
             "convergence": {"sum_cost": float(red_host[:, 0].sum()), "max_prim": float(red_host[:, 1].max()),
                             "max_dual": float(red_host[:, 2].max()), "active": float(red_host[:, 3].sum()),
                             "failed": float(red_host[:, 4].sum())},

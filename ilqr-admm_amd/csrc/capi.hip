@@ -10,6 +10,7 @@ namespace isls {
 // (bench.py reads these: average launch duration of the dominant kernel for the roofline line)
 struct Timing {
     bool on = false;
+    bool paused = false;           // events are recorded only while on && !paused (bench.py samples every k-th step)
     static constexpr int kKinds = 5;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[kKinds];
     size_t used[kKinds] = {0, 0, 0, 0, 0};
@@ -22,7 +23,7 @@ struct ScopedTimer {
     hipEvent_t stop = nullptr;
     ScopedTimer(int kind_, hipStream_t s_) : kind(kind_), s(s_)
     {
-        if (!g_timing.on) return;
+        if (!g_timing.on || g_timing.paused) return;
         auto &pool = g_timing.ev[kind];
         size_t &u = g_timing.used[kind];
         if (u == pool.size()) {
@@ -177,8 +178,17 @@ ISLS_API const char *isls_error_string(int code)
 ISLS_API int isls_timing_enable(int on)
 {
     g_timing.on = on != 0;
+    g_timing.paused = false;
     if (on)   // (re)start a measurement window; disabling keeps the recorded events readable
         for (int k = 0; k < Timing::kKinds; ++k) g_timing.used[k] = 0;
+    return 0;
+}
+
+// Suspend / resume event recording inside a measurement window without resetting it (an event pair per launch
+// costs a few microseconds of queue bubbles; sampling every k-th step keeps the timed region representative).
+ISLS_API int isls_timing_pause(int paused)
+{
+    g_timing.paused = paused != 0;
     return 0;
 }
 

@@ -124,7 +124,8 @@ class OuterArgs(C.Structure):
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
-           ["isls_ff_segments", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_read_ms"]
+           ["isls_ff_segments", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_pause",
+            "isls_timing_read_ms"]
 
 
 class IslsError(RuntimeError):

@@ -341,6 +341,7 @@ const char *isls_error_string(int code);
  * kernel family on `stream`. kind: 0 gain, 1 ff, 2 rollout, 3 admm, 4 ff_prepare.  Returns ms of the last
  * completed timed launch set, or <0 if timing is disabled. */
 int isls_timing_enable(int on);
+int isls_timing_pause(int paused);   /* suspend / resume recording without resetting the window */
 double isls_timing_read_ms(int kind, int *count);
 
 #ifdef __cplusplus
