@@ -19,11 +19,23 @@ struct AdmmP {
     View<T> x_lo, x_hi, u_lo, u_hi;
     T *res, *res_prev;
     int32_t *active, *iters;
+    const T *x_work, *u_work;      // ISLS_PROJ_SETS: the projected argument, produced by admm_argument_kernel + project_rows
 };
+
+// relax*x + (1-relax)*z + lmb of one block, written out for the set projection (ISLS_PROJ_SETS)
+template <typename T>
+__global__ __launch_bounds__(64) void admm_argument_kernel(int N, int d, T relax, const T *x, const T *z, const T *l, T *work,
+                                                           const int32_t *active)
+{
+    const int b = blockIdx.x;
+    if (active && active[b] == 0) return;
+    const int64_t o = (int64_t)b * N * d;
+    for (int e = threadIdx.x; e < N * d; e += kWave) work[o + e] = (relax * x[o + e] + (T(1) - relax) * z[o + e]) + l[o + e];
+}
 
 template <typename T>
 __device__ __forceinline__ void admm_block(int N, int d, int proj, T relax, const T *x, T *z, T *l,
-                                           const View<T> &lo, const View<T> &hi, int b, T &p2, T &d2)
+                                           const View<T> &lo, const View<T> &hi, const T *work, int b, T &p2, T &d2)
 {
     p2 = T(0); d2 = T(0);
     const int cnt = N * d;
@@ -36,6 +48,8 @@ __device__ __forceinline__ void admm_block(int N, int d, int proj, T relax, cons
             const T lo_v = lo.at(b, t)[i], hi_v = hi.at(b, t)[i];
             zn = arg < lo_v ? lo_v : arg;                            // np.clip
             zn = zn > hi_v ? hi_v : zn;
+        } else if (proj == ISLS_PROJ_SETS) {
+            zn = work[e];
         }
         const T r = xv - zn;                                         // admm.py:51
         l[e] = lv + r;                                               // admm.py:52
@@ -55,12 +69,12 @@ __global__ __launch_bounds__(64) void admm_update_kernel(AdmmP<T> p)
     T prim = T(0), dual = T(0), p2, d2;
     if (p.zx) {
         const int64_t o = (int64_t)b * p.N * p.n;
-        admm_block<T>(p.N, p.n, p.proj_x, p.relax, p.xx + o, p.zx + o, p.lx + o, p.x_lo, p.x_hi, b, p2, d2);
+        admm_block<T>(p.N, p.n, p.proj_x, p.relax, p.xx + o, p.zx + o, p.lx + o, p.x_lo, p.x_hi, p.x_work ? p.x_work + o : nullptr, b, p2, d2);
         prim += sqrt(p2); dual += sqrt(d2);
     }
     if (p.zu) {
         const int64_t o = (int64_t)b * p.N * p.m;
-        admm_block<T>(p.N, p.m, p.proj_u, p.relax, p.xu + o, p.zu + o, p.lu + o, p.u_lo, p.u_hi, b, p2, d2);
+        admm_block<T>(p.N, p.m, p.proj_u, p.relax, p.xu + o, p.zu + o, p.lu + o, p.u_lo, p.u_hi, p.u_work ? p.u_work + o : nullptr, b, p2, d2);
         prim += sqrt(p2); dual += sqrt(d2);
     }
     if (threadIdx.x == 0) {
@@ -90,9 +104,29 @@ int launch_admm(const isls_admm_args &a, hipStream_t s)
     if (a.zu && (!a.lu || !a.xu)) return ISLS_ERR_ARG;
     if (a.zx && a.proj_x == ISLS_PROJ_BOX && (!a.x_lo.p || !a.x_hi.p)) return ISLS_ERR_ARG;
     if (a.zu && a.proj_u == ISLS_PROJ_BOX && (!a.u_lo.p || !a.u_hi.p)) return ISLS_ERR_ARG;
-    if ((a.proj_x != ISLS_PROJ_NONE && a.proj_x != ISLS_PROJ_BOX) || (a.proj_u != ISLS_PROJ_NONE && a.proj_u != ISLS_PROJ_BOX))
+    if (a.proj_x < ISLS_PROJ_NONE || a.proj_x > ISLS_PROJ_SETS || a.proj_u < ISLS_PROJ_NONE || a.proj_u > ISLS_PROJ_SETS)
         return ISLS_ERR_UNSUPPORTED;
+    if (a.zx && a.proj_x == ISLS_PROJ_SETS && (!a.x_sets || !a.x_work || a.x_col0 < 0 || a.x_col0 + a.x_sets->d > a.n)) return ISLS_ERR_ARG;
+    if (a.zu && a.proj_u == ISLS_PROJ_SETS && (!a.u_sets || !a.u_work || a.u_col0 < 0 || a.u_col0 + a.u_sets->d > a.m)) return ISLS_ERR_ARG;
     if (a.B == 0) return ISLS_OK;
+    // set projections: argument -> scratch, project_set_convex over the time steps of the coordinate block in place
+    for (int blk = 0; blk < 2; ++blk) {
+        const bool isx = blk == 0;
+        if (!(isx ? a.zx : a.zu) || (isx ? a.proj_x : a.proj_u) != ISLS_PROJ_SETS) continue;
+        const int d = isx ? a.n : a.m, col0 = isx ? a.x_col0 : a.u_col0;
+        T *work = (T *)(isx ? a.x_work : a.u_work);
+        hipLaunchKernelGGL((admm_argument_kernel<T>), dim3(a.B), dim3(64), 0, s, a.N, d, (T)a.relax,
+                           (const T *)(isx ? a.xx : a.xu), (const T *)(isx ? a.zx : a.zu), (const T *)(isx ? a.lx : a.lu), work,
+                           (const int32_t *)a.active);
+        isls_project_args pr = *(isx ? a.x_sets : a.u_sets);
+        pr.P = a.B; pr.R = a.N;
+        pr.y_in = work + col0; pr.y_out = work + col0;
+        pr.in_sp = pr.out_sp = (int64_t)a.N * d;
+        pr.in_sr = pr.out_sr = d;
+        pr.iters = nullptr; pr.active = a.active;
+        const int rc = launch_project<T>(pr, s);
+        if (rc != ISLS_OK) return rc;
+    }
     AdmmP<T> p;
     p.B = a.B; p.N = a.N; p.n = a.n; p.m = a.m; p.proj_x = a.proj_x; p.proj_u = a.proj_u;
     p.relax = (T)a.relax; p.tol_abs = (T)a.tol_abs; p.tol_rel = (T)a.tol_rel;
@@ -100,6 +134,8 @@ int launch_admm(const isls_admm_args &a, hipStream_t s)
     p.zx = (T *)a.zx; p.lx = (T *)a.lx; p.zu = (T *)a.zu; p.lu = (T *)a.lu;
     p.x_lo = View<T>(a.x_lo); p.x_hi = View<T>(a.x_hi); p.u_lo = View<T>(a.u_lo); p.u_hi = View<T>(a.u_hi);
     p.res = (T *)a.res; p.res_prev = (T *)a.res_prev; p.active = a.active; p.iters = a.iters;
+    p.x_work = a.proj_x == ISLS_PROJ_SETS ? (const T *)a.x_work : nullptr;
+    p.u_work = a.proj_u == ISLS_PROJ_SETS ? (const T *)a.u_work : nullptr;
     hipLaunchKernelGGL((admm_update_kernel<T>), dim3(a.B), dim3(64), 0, s, p);
     return check_launch();
 }

@@ -127,6 +127,14 @@ ISLS_API int isls_linearize_f32(const isls_linearize_args *a, void *stream)
 {
     return a ? launch_linearize<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
+ISLS_API int isls_project_rows_f64(const isls_project_args *a, void *stream)
+{
+    return a ? launch_project<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_project_rows_f32(const isls_project_args *a, void *stream)
+{
+    return a ? launch_project<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
 ISLS_API int isls_accept_step_f64(const isls_accept_args *a, void *stream)
 {
     return a ? launch_accept<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;

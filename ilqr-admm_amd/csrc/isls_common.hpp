@@ -171,6 +171,7 @@ bool ff_seg_enabled(const isls_ffseg &sg);
 int ff_segments(int N, int nseg_req, int *seg_len);
 template <typename T> int launch_rollout(const isls_rollout_args &a, hipStream_t s);
 template <typename T> int launch_admm(const isls_admm_args &a, hipStream_t s);
+template <typename T> int launch_project(const isls_project_args &a, hipStream_t s);
 template <typename T> int launch_expand(const isls_expand_args &a, hipStream_t s);
 template <typename T> int launch_linearize(const isls_linearize_args &a, hipStream_t s);
 template <typename T> int launch_accept(const isls_accept_args &a, hipStream_t s);

@@ -1,0 +1,257 @@
+// projections.hpp -- device restatement of the row-wise projections of isls/projections.py and of
+// project_set_convex (inner ADMM onto an intersection of sets), shared by project.hip and sls_admm.hip.
+//
+//   ISLS_SET_BOX       np.clip(y, lo, hi)                                   isls/projections.py:7-11
+//   ISLS_SET_SOC_UNIT  (z,t) -> ||z|| <= t, project_soc_unit_batch          isls/projections.py:140-162
+//   ISLS_SET_SQUARE    l <= ||W(y[:q]-c)||_inf <= u on the first q entries  isls/projections.py:256-266 and the
+//                      keep-out rectangles of notebooks/Car/Iterative LQR with state constraints.ipynb cell 18
+//   project_set_convex                                                      isls/projections.py:289-374
+// Every array of a row lives in registers: all loops run to the compile-time maxima with constant indices and
+// are predicated on the runtime dimension (a runtime index into a per-lane array would go to scratch memory).
+#pragma once
+#include "isls_common.hpp"
+
+namespace isls {
+
+constexpr int kMaxRowDim = ISLS_MAX_ROW_DIM;   // d
+constexpr int kMaxSetDim = ISLS_MAX_SET_DIM;   // dim_i of A_i y + b_i
+constexpr int kMaxSets = ISLS_MAX_SETS;
+
+template <typename T>
+struct CSet {
+    int kind, dim;
+    const T *A, *b, *par;          // this problem's A [dim,d], b [dim], parameters
+};
+
+// numpy sign(): 0 for 0 (project_square_batch puts 0 on the arg-max entry of an all-zero row)
+template <typename T> __device__ __forceinline__ T np_sign(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0)); }
+
+// v[0..dim) <- primitive projection of v (in place)
+template <typename T>
+__device__ __forceinline__ void project_primitive(int kind, int dim, const T *par, T (&v)[kMaxSetDim])
+{
+    if (kind == ISLS_SET_BOX) {                                // par = lo[dim], hi[dim]
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < dim) {
+                const T lo = par[i], hi = par[dim + i];
+                const T a = v[i] < lo ? lo : v[i];             // np.clip = minimum(maximum(x, lo), hi)
+                v[i] = a > hi ? hi : a;
+            }
+    } else if (kind == ISLS_SET_SOC_UNIT) {                    // z = v[:dim-1], t = v[dim-1]
+        T t = T(0), ss = T(0);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) {
+            if (i < dim - 1) ss += v[i] * v[i];
+            if (i == dim - 1) t = v[i];
+        }
+        const T zn = sqrt(ss);
+        const bool cond1 = (zn <= -t) || (t < T(0));
+        const bool cond2 = (zn > t) || (zn > -t);
+        const bool cond3 = zn <= t;
+        const T tmp = (zn + t) / T(2);
+        const T sc = tmp / (zn + T(1e-30));
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) {
+            if (i < dim) {
+                const bool is_t = i == dim - 1;
+                T o = v[i];
+                if (cond2) o = is_t ? tmp : tmp * v[i] / (zn + T(1e-30));   // tmp[:,None] * z / (||z|| + 1e-30)
+                if (cond1) o = T(0);
+                if (cond3) o = v[i];
+                v[i] = o;
+            }
+        }
+        (void)sc;
+    } else if (kind == ISLS_SET_SQUARE) {                      // par = q, l, u, c[q], W[q*q], Winv[q*q]
+        const int q = (int)par[0];
+        const T l = par[1], u = par[2];
+        const T *c = par + 3, *W = c + q, *Wi = W + q * q;
+        T y[kMaxSetDim], w[kMaxSetDim];
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) y[i] = i < q ? v[i] - c[i] : T(0);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) {                 // w = y @ W.T
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < kMaxSetDim; ++j)
+                if (i < q && j < q) acc += y[j] * W[i * q + j];
+            w[i] = acc;
+        }
+        int jmax = 0;                                          // first arg-max of |w| (np.argmax)
+        T amax = T(-1);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < q) {
+                const T a = w[i] < T(0) ? -w[i] : w[i];
+                if (a > amax) { amax = a; jmax = i; }
+            }
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < q) {
+                T o = w[i];
+                if (amax < l && i == jmax) o = l * np_sign(w[i]);
+                o = o > u ? u : o;                             // maximum(minimum(z, u), -u)
+                o = o < -u ? -u : o;
+                w[i] = o;
+            }
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < q) {                                       // back: w @ Winv.T + c
+                T acc = T(0);
+#pragma unroll
+                for (int j = 0; j < kMaxSetDim; ++j)
+                    if (j < q) acc += w[j] * Wi[i * q + j];
+                v[i] = acc + c[i];
+            }
+    }
+}
+
+// inverse of the d x d matrix M (SPD: I + rho sum A'A) by Gauss-Jordan without pivoting, in registers
+template <typename T, int D>
+__device__ __forceinline__ void invert_spd(T (&M)[D][D], T (&Inv)[D][D])
+{
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Inv[i][j] = i == j ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const T piv = T(1) / M[k][k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) { M[k][j] *= piv; Inv[k][j] *= piv; }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i != k) {
+                const T f = M[i][k];
+#pragma unroll
+                for (int j = 0; j < D; ++j) { M[i][j] -= f * M[k][j]; Inv[i][j] -= f * Inv[k][j]; }
+            }
+    }
+}
+
+// project_set_convex for ONE row x0[D] (isls/projections.py:289-374).  `block_max(a, b)` must return the maxima of
+// a and b over every row of the same call (the reference stops all rows of a call together: np.max over rows and
+// sets); rows that do not exist pass zeros.  Returns the number of iterations run.
+template <typename T, int D, typename BlockMax>
+__device__ __forceinline__ int project_set_convex_row(const T (&x0)[D], int nsets, const CSet<T> (&sets)[kMaxSets], T rho,
+                                                      int max_iter, T threshold, T (&x)[D], BlockMax &&block_max)
+{
+    T z[kMaxSets][kMaxSetDim], lmb[kMaxSets][kMaxSetDim];
+    T M[D][D], Linv[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) M[i][j] = T(0);
+#pragma unroll
+    for (int s = 0; s < kMaxSets; ++s) {
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) { z[s][i] = T(0); lmb[s][i] = T(0); }
+        if (s < nsets) {
+            const T *A = sets[s].A, *b = sets[s].b;
+            const int dim = sets[s].dim;
+#pragma unroll
+            for (int i = 0; i < kMaxSetDim; ++i)
+                if (i < dim) {                                 // z_i = A_i x0 + b_i ; l_side_add += A_i' A_i
+                    T acc = T(0);
+#pragma unroll
+                    for (int j = 0; j < D; ++j) acc += A[i * D + j] * x0[j];
+                    z[s][i] = acc + b[i];
+#pragma unroll
+                    for (int j = 0; j < D; ++j)
+#pragma unroll
+                        for (int k = 0; k < D; ++k) M[j][k] += A[i * D + j] * A[i * D + k];
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) M[i][j] = (i == j ? T(1) : T(0)) + rho * M[i][j];
+    invert_spd<T, D>(M, Linv);
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] = x0[j];
+
+    T prim_g = T(1e5), dual_g = T(1e5);
+    int it = 0;
+    for (int j = 0; j < max_iter; ++j) {
+        ++it;
+        T rs[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) rs[k] = T(0);
+#pragma unroll
+        for (int s = 0; s < kMaxSets; ++s)
+            if (s < nsets) {
+                const T *A = sets[s].A, *b = sets[s].b;
+                const int dim = sets[s].dim;
+#pragma unroll
+                for (int i = 0; i < kMaxSetDim; ++i)
+                    if (i < dim) {
+                        const T w = (-b[i] + z[s][i]) - lmb[s][i];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) rs[k] += A[i * D + k] * w;
+                    }
+            }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += Linv[i][k] * (x0[k] + rho * rs[k]);
+            x[i] = acc;
+        }
+        const T prev_prim = prim_g, prev_dual = dual_g;
+        T prim_m = T(0), dual_m = T(0);
+#pragma unroll
+        for (int s = 0; s < kMaxSets; ++s)
+            if (s < nsets) {
+                const T *A = sets[s].A, *b = sets[s].b;
+                const int dim = sets[s].dim;
+                T axb[kMaxSetDim], v[kMaxSetDim];
+#pragma unroll
+                for (int i = 0; i < kMaxSetDim; ++i) {
+                    T acc = T(0);
+                    if (i < dim) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc += A[i * D + k] * x[k];
+                        acc += b[i];
+                    }
+                    axb[i] = acc;
+                    v[i] = acc + lmb[s][i];
+                }
+                project_primitive<T>(sets[s].kind, dim, sets[s].par, v);
+                T pn = T(0), dres[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) dres[k] = T(0);
+#pragma unroll
+                for (int i = 0; i < kMaxSetDim; ++i)
+                    if (i < dim) {
+                        const T pr = axb[i] - v[i];
+                        const T dz = v[i] - z[s][i];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) dres[k] += A[i * D + k] * dz;
+                        lmb[s][i] += pr;
+                        z[s][i] = v[i];
+                        pn += pr * pr;
+                    }
+                T dn = T(0);
+#pragma unroll
+                for (int k = 0; k < D; ++k) dn += (rho * dres[k]) * (rho * dres[k]);
+                pn = sqrt(pn);
+                dn = sqrt(dn);
+                prim_m = pn > prim_m ? pn : prim_m;
+                dual_m = dn > dual_m ? dn : dual_m;
+            }
+        block_max(prim_m, dual_m);                             // -> maxima over every row of the call
+        prim_g = prim_m;
+        dual_g = dual_m;
+        if (prim_g < threshold && dual_g < threshold) break;
+        if (j != max_iter - 1) {
+            const T pc = fabs(prev_prim - prim_g) / (prev_prim + T(1e-30));
+            const T dc = fabs(prev_dual - dual_g) / (prev_dual + T(1e-30));
+            if (pc < T(1e-5) && dc < T(1e-5)) break;
+        }
+    }
+    return it;
+}
+
+}  // namespace isls

@@ -22,7 +22,7 @@ ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
 MODEL_LTI, MODEL_ARM3R, MODEL_CAR, MODEL_DI = 0, 1, 2, 3
 RO_NAN_TO_1E5, RO_ACCEPT_TEST, RO_ABSOLUTE = 1, 2, 4
-PROJ_NONE, PROJ_BOX = 0, 1
+PROJ_NONE, PROJ_BOX, PROJ_SETS = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libisls_hip.so")
@@ -85,7 +85,9 @@ class AdmmArgs(C.Structure):
                 ("xx", C.c_void_p), ("xu", C.c_void_p),
                 ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
                 ("x_lo", View), ("x_hi", View), ("u_lo", View), ("u_hi", View),
-                ("res", C.c_void_p), ("res_prev", C.c_void_p), ("active", C.c_void_p), ("iters", C.c_void_p)]
+                ("res", C.c_void_p), ("res_prev", C.c_void_p), ("active", C.c_void_p), ("iters", C.c_void_p),
+                ("x_sets", C.c_void_p), ("u_sets", C.c_void_p), ("x_col0", C.c_int32), ("u_col0", C.c_int32),
+                ("x_work", C.c_void_p), ("u_work", C.c_void_p)]
 
 
 class ExpandArgs(C.Structure):
@@ -115,6 +117,20 @@ class AcceptArgs(C.Structure):
                 ("tol_cost", C.c_double), ("tol_osc", C.c_double), ("outer_active", C.c_void_p)]
 
 
+class CSet(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dim", C.c_int32), ("A", C.c_void_p), ("b", C.c_void_p), ("par", C.c_void_p),
+                ("A_sp", C.c_int64), ("b_sp", C.c_int64), ("par_sp", C.c_int64)]
+
+
+class ProjectArgs(C.Structure):
+    _fields_ = [("P", C.c_int32), ("R", C.c_int32), ("d", C.c_int32), ("nsets", C.c_int32),
+                ("max_iter", C.c_int32), ("_pad", C.c_int32), ("rho", C.c_double), ("threshold", C.c_double),
+                ("sets", CSet * 4),
+                ("y_in", C.c_void_p), ("in_sp", C.c_int64), ("in_sr", C.c_int64),
+                ("y_out", C.c_void_p), ("out_sp", C.c_int64), ("out_sr", C.c_int64),
+                ("iters", C.c_void_p), ("active", C.c_void_p)]
+
+
 class OuterArgs(C.Structure):
     _fields_ = [("gain", GainArgs), ("ff", FfArgs), ("ro", RolloutArgs), ("admm", AdmmArgs),
                 ("J", C.c_int32), ("skip_gain", C.c_int32), ("log", C.c_void_p), ("outer_active", C.c_void_p)]
@@ -122,10 +138,14 @@ class OuterArgs(C.Structure):
 
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
-            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "expand_quadratic", "linearize",
+            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
            ["isls_ff_segments", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_pause",
             "isls_timing_read_ms"]
+
+
+SET_BOX, SET_SOC_UNIT, SET_SQUARE = 1, 2, 3
+MAX_ROW_DIM, MAX_SET_DIM, MAX_SETS = 4, 5, 4
 
 
 class IslsError(RuntimeError):
@@ -345,12 +365,20 @@ class Kernels:
 
     @staticmethod
     def admm_args(xx, xu, res, zx=None, lx=None, zu=None, lu=None, x_lo=None, x_hi=None, u_lo=None, u_hi=None,
-                  relax=1.0, tol_abs=0.0, tol_rel=0.0, res_prev=None, active=None, iters=None):
+                  relax=1.0, tol_abs=0.0, tol_rel=0.0, res_prev=None, active=None, iters=None,
+                  x_sets=None, x_col0=0, x_work=None, u_sets=None, u_col0=0, u_work=None):
+        """x_sets / u_sets: a ProjectArgs descriptor (project_args) => ISLS_PROJ_SETS on that block, with the
+        [B,N,.] scratch x_work / u_work and the first projected coordinate x_col0 / u_col0."""
         B, N, n = xx.shape
         m = xu.shape[2]
         a = AdmmArgs(B=B, N=N, n=n, m=m, relax=float(relax), tol_abs=float(tol_abs), tol_rel=float(tol_rel))
-        a.proj_x = PROJ_BOX if x_lo is not None else PROJ_NONE
-        a.proj_u = PROJ_BOX if u_lo is not None else PROJ_NONE
+        a.proj_x = PROJ_SETS if x_sets is not None else (PROJ_BOX if x_lo is not None else PROJ_NONE)
+        a.proj_u = PROJ_SETS if u_sets is not None else (PROJ_BOX if u_lo is not None else PROJ_NONE)
+        if x_sets is not None:
+            a.x_sets, a.x_col0, a.x_work = C.addressof(x_sets), int(x_col0), _ptr(_dense(x_work, (B, N, n), "x_work"))
+        if u_sets is not None:
+            a.u_sets, a.u_col0, a.u_work = C.addressof(u_sets), int(u_col0), _ptr(_dense(u_work, (B, N, m), "u_work"))
+        a._keep = (x_sets, u_sets)
         a.xx, a.xu = _ptr(_dense(xx, (B, N, n), "xx")), _ptr(_dense(xu, (B, N, m), "xu"))
         a.zx, a.lx = _ptr(_dense(zx, (B, N, n), "zx")), _ptr(_dense(lx, (B, N, n), "lx"))
         a.zu, a.lu = _ptr(_dense(zu, (B, N, m), "zu")), _ptr(_dense(lu, (B, N, m), "lu"))
@@ -368,6 +396,46 @@ class Kernels:
     def riccati_ff(self, *args, stream=None, **kw):
         a = self.ff_args(*args, **kw)
         return self._call("riccati_ff", _sfx(args[4]), a, stream)
+
+    @staticmethod
+    def project_args(y_in, y_out, sets, rho=1.0, max_iter=200, threshold=1e-4, iters=None, active=None, cols=None):
+        """isls_project_args for rows y[P,R,D]; `cols=(c0, d)` projects the coordinate block [c0, c0+d) of every row
+        (the rest of the row is not touched).  sets: list of dicts kind, dim, A[dim,d] | [P,dim,d], b, par (arrays of
+        the dtype of y; a leading P axis gives per-problem operands)."""
+        P, R, D = y_in.shape
+        c0, d = cols if cols is not None else (0, D)
+        if not (1 <= d <= MAX_ROW_DIM) or c0 < 0 or c0 + d > D or not (1 <= len(sets) <= MAX_SETS):
+            raise ValueError("project_rows: unsupported row / set dimensions")
+        _dense(y_in, (P, R, D), "y_in"), _dense(y_out, (P, R, D), "y_out")
+        esz = y_in.element_size() if _is_torch(y_in) else y_in.itemsize
+        a = ProjectArgs(P=P, R=R, d=d, nsets=len(sets), max_iter=int(max_iter), rho=float(rho), threshold=float(threshold))
+        a.y_in, a.y_out = _ptr(y_in) + c0 * esz, _ptr(y_out) + c0 * esz
+        a.in_sp = a.out_sp = R * D
+        a.in_sr = a.out_sr = D
+        keep = []
+        for i, st in enumerate(sets):
+            c = a.sets[i]
+            c.kind, c.dim = int(st["kind"]), int(st["dim"])
+            for name, core in (("A", (c.dim, d)), ("b", (c.dim,)), ("par", None)):
+                arr = st.get(name)
+                if arr is None:
+                    continue
+                per = arr.ndim == (len(core) + 1 if core is not None else 2)
+                if core is not None:
+                    _dense(arr, ((P,) + core) if per else core, f"sets[{i}].{name}")
+                elif per and arr.shape[0] != P:
+                    raise ValueError(f"sets[{i}].par: leading axis must be P")
+                setattr(c, name, _ptr(arr))
+                setattr(c, name + "_sp", int(arr[0].numel() if _is_torch(arr) else arr[0].size) if per else 0)
+                keep.append(arr)
+        a.iters, a.active = _ptr(iters), _ptr(active)
+        a._keep = keep
+        a._spec = dict(sets=sets, rho=rho, max_iter=max_iter, threshold=threshold, cols=(c0, d))   # to rebuild elsewhere
+        return a
+
+    def project_rows(self, y_in, y_out, sets, stream=None, **kw):
+        a = self.project_args(y_in, y_out, sets, **kw)
+        return self._call("project_rows", _sfx(y_in), a, stream)
 
     def riccati_ff_prepare(self, *args, stream=None, **kw):
         a = self.ff_prepare_args(*args, **kw)

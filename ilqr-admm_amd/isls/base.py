@@ -11,7 +11,7 @@ import torch
 
 from . import _capi as capi
 from .engine import ALPHAS, Engine
-from .projections import Box, identify_box
+from .projections import Box, ConvexSets, identify_box
 from .utils import find_mus, find_precs
 
 
@@ -72,7 +72,9 @@ class Base:
         """project_x / project_u argument -> Box descriptor (device path), callable (host path) or None."""
         if project is False or project is None:
             return None
-        if isinstance(project, Box):
+        if isinstance(project, (Box, ConvexSets)):
+            if isinstance(project, ConvexSets) and project.dim != d:
+                raise ValueError(f"ConvexSets acts on rows of dimension {project.dim}, this block has {d}")
             return project
         if callable(project):
             box = identify_box(project, self.N * d)

@@ -83,6 +83,8 @@ class Engine:
         self.u_std = 0.0
         self.Qr = self.Rr = self.wq = self.wr = None
         self.x_lo = self.x_hi = self.u_lo = self.u_hi = None
+        self.x_sets = self.u_sets = self.x_work = self.u_work = None
+        self.x_col0 = self.u_col0 = 0
         self.relax = 1.0
         self.solve_mode = capi.SOLVE_CHOL
         self._outer_args = None
@@ -118,8 +120,9 @@ class Engine:
         self.outer_active.fill_(1)
         self.status.zero_()
 
-    def set_admm(self, rho_x=None, rho_u=None, x_box=None, u_box=None, relax=1.0):
-        """ADMM weights (Base.compute_Rr_Qr, isls/base.py:55-79, dp=True form) and box constraint sets."""
+    def set_admm(self, rho_x=None, rho_u=None, x_box=None, u_box=None, relax=1.0, x_sets=None, u_sets=None):
+        """ADMM weights (Base.compute_Rr_Qr, isls/base.py:55-79, dp=True form) and the constraint sets: boxes
+        (lo, hi) or `isls.projections.ConvexSets` (project_set_convex over the time steps, on the device)."""
         B, N, n, m = self.B, self.N, self.n, self.m
         z = lambda *s: torch.zeros(*s, dtype=self.dtype, device=self.device)      # noqa: E731
 
@@ -133,11 +136,12 @@ class Engine:
                 return r.reshape(1, d, d)
             return r                                   # [N,d,d] or [B,N,d,d]
 
-        self.Qr = weights(rho_x, n) if x_box is not None else None
-        self.Rr = weights(rho_u, m) if u_box is not None else None
-        if x_box is not None and self.Qr is None:
+        has_x, has_u = x_box is not None or x_sets is not None, u_box is not None or u_sets is not None
+        self.Qr = weights(rho_x, n) if has_x else None
+        self.Rr = weights(rho_u, m) if has_u else None
+        if has_x and self.Qr is None:
             raise ValueError("project_x needs rho_x")
-        if u_box is not None and self.Rr is None:
+        if has_u and self.Rr is None:
             raise ValueError("project_u needs rho_u")
         # (dx*dx)@Qr precedence (isls/isls.py:473,476): the AL weights are the row sums
         self.wq = None if self.Qr is None else self.Qr.sum(-1).contiguous()
@@ -155,10 +159,30 @@ class Engine:
 
         self.x_lo, self.x_hi = bounds(x_box, n)
         self.u_lo, self.u_hi = bounds(u_box, m)
-        self.zx, self.lx = (z(B, N, n), z(B, N, n)) if x_box is not None else (None, None)
-        self.zu, self.lu = (z(B, N, m), z(B, N, m)) if u_box is not None else (None, None)
+        self.zx, self.lx = (z(B, N, n), z(B, N, n)) if has_x else (None, None)
+        self.zu, self.lu = (z(B, N, m), z(B, N, m)) if has_u else (None, None)
         self.relax = float(relax)
         self._outer_args = None
+
+        def device_sets(cs, d):
+            """ConvexSets -> (isls_project_args descriptor, first column, scratch) with the operands on the device."""
+            if cs is None:
+                return None, 0, None
+            if cs.dim != d:
+                raise ValueError(f"constraint set is defined on rows of dimension {cs.dim}, expected {d}")
+            work = z(B, N, d)
+            sets = [{k: (self._t(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+                    for st in cs.sets]
+            desc = capi.Kernels.project_args(work, work, sets, rho=cs.rho, max_iter=cs.max_iter, threshold=cs.threshold,
+                                             cols=cs.cols)
+            return desc, cs.cols[0], work
+
+        self.x_sets, self.x_col0, self.x_work = device_sets(x_sets, n)
+        self.u_sets, self.u_col0, self.u_work = device_sets(u_sets, m)
+        if x_sets is not None:
+            self.x_lo = self.x_hi = None
+        if u_sets is not None:
+            self.u_lo = self.u_hi = None
 
     # ---- single kernels -----------------------------------------------------------------------------------
     def evaluate_cost(self):
@@ -197,7 +221,8 @@ class Engine:
         self.kern.admm_update(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
                               x_lo=self.x_lo, x_hi=self.x_hi, u_lo=self.u_lo, u_hi=self.u_hi, relax=self.relax,
                               tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=active,
-                              iters=self.admm_iters, stream=_stream_ptr())
+                              iters=self.admm_iters, x_sets=self.x_sets, x_col0=self.x_col0, x_work=self.x_work,
+                              u_sets=self.u_sets, u_col0=self.u_col0, u_work=self.u_work, stream=_stream_ptr())
 
     # ---- time-parallel feed-forward pass (isls_ffseg): operators from the gain pass, reused by J ADMM iterations
     def ff_seg(self, nseg_requested=None):
@@ -236,7 +261,8 @@ class Engine:
         admm = K.admm_args(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
                            x_lo=self.x_lo, x_hi=self.x_hi, u_lo=self.u_lo, u_hi=self.u_hi, relax=self.relax,
                            tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=self.admm_active,
-                           iters=self.admm_iters)
+                           iters=self.admm_iters, x_sets=self.x_sets, x_col0=self.x_col0, x_work=self.x_work,
+                           u_sets=self.u_sets, u_col0=self.u_col0, u_work=self.u_work)
         self._outer_args = capi.OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=0)
         self._outer_args.log = capi._ptr(log)
         self._outer_args.outer_active = capi._ptr(self.outer_active)

@@ -21,7 +21,7 @@ from . import _capi as capi
 from .admm import ADMM
 from .base import ALPHAS, Base
 from .models import Model
-from .projections import Box
+from .projections import Box, ConvexSets
 
 
 class iSLS(Base):
@@ -268,12 +268,15 @@ class iSLS(Base):
         tol = threshold if threshold is not None else tol
         e = self.engine
         px, pu = self._projection(project_x, self.x_dim), self._projection(project_u, self.u_dim)
-        host_proj = (px is not None and not isinstance(px, Box)) or (pu is not None and not isinstance(pu, Box))
-        xb = px.bounds(self.N, self.x_dim) if isinstance(px, Box) else ((-np.inf, np.inf) if px is not None else None)
-        ub = pu.bounds(self.N, self.u_dim) if isinstance(pu, Box) else ((-np.inf, np.inf) if pu is not None else None)
+        on_device = (Box, ConvexSets)
+        host_proj = (px is not None and not isinstance(px, on_device)) or (pu is not None and not isinstance(pu, on_device))
+        xs = px if isinstance(px, ConvexSets) and not host_proj else None
+        us = pu if isinstance(pu, ConvexSets) and not host_proj else None
+        xb = px.bounds(self.N, self.x_dim) if isinstance(px, Box) else ((-np.inf, np.inf) if px is not None and xs is None else None)
+        ub = pu.bounds(self.N, self.u_dim) if isinstance(pu, Box) else ((-np.inf, np.inf) if pu is not None and us is None else None)
         zx_keep, zu_keep = e.zx, e.zu
         e.set_admm(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None,
-                   x_box=xb, u_box=ub, relax=alpha)
+                   x_box=xb, u_box=ub, relax=alpha, x_sets=xs, u_sets=us)
         J = int(max_admm_iter)
         logbuf = torch.zeros(J, self.batch, 2, dtype=e.dtype, device=e.device)
         e.outer_active.fill_(1)

@@ -35,6 +35,68 @@ class Box:
         return expand(self.lo), expand(self.hi)
 
 
+SET_BOX, SET_SOC_UNIT, SET_SQUARE = 1, 2, 3     # include/isls_hip.h ISLS_SET_*
+
+
+class ConvexSets:
+    """Intersection of convex(ish) sets acting on the coordinate block [c0, c0+d) of every time-step row of a flat
+    [N*dim] vector, evaluated with `project_set_convex` (isls/projections.py:289-374) over the N rows of one call.
+
+    It is what the reference's notebooks assemble by hand from `project_set_convex`, `project_soc_unit` and
+    `project_square_batch` closures (Car "state constraints" notebook cell 18, Double-integrator "control bounds"
+    cell 15).  Calling it on a numpy vector runs the numpy operators below (host route); the solvers recognise the
+    object and run the same iteration on the device instead (ISLS_PROJ_SETS / isls_project_rows).
+
+    sets: list of dict(kind=SET_*, dim=, A=[dim,d], b=[dim], par=[...]) -- `par` as documented in include/isls_hip.h.
+    """
+
+    def __init__(self, dim, cols, sets, rho=1.0, max_iter=200, threshold=1e-4):
+        self.dim, self.cols, self.sets = int(dim), (int(cols[0]), int(cols[1])), list(sets)
+        self.rho, self.max_iter, self.threshold = float(rho), int(max_iter), float(threshold)
+
+    @staticmethod
+    def _primitive(st):
+        kind, par = st["kind"], st.get("par")
+        if kind == SET_BOX:
+            d = st["dim"]
+            return lambda v: project_bound(v, par[:d], par[d:2 * d])
+        if kind == SET_SOC_UNIT:
+            return project_soc_unit
+        q = int(par[0])
+        l, u, c = par[1], par[2], par[3:3 + q]
+        W, Wi = par[3 + q:3 + q + q * q].reshape(q, q), par[3 + q + q * q:3 + q + 2 * q * q].reshape(q, q)
+
+        def square(v):
+            out = np.array(v, dtype=np.float64, copy=True)
+            out[:, :q] = project_square_batch((out[:, :q] - c) @ W.T, l, u) @ Wi.T + c
+            return out
+        return square
+
+    def __call__(self, flat):
+        y = np.array(flat, dtype=np.float64, copy=True).reshape(-1, self.dim)
+        c0, d = self.cols
+        blk = project_set_convex(y[:, c0:c0 + d].copy(), [np.asarray(s["A"], dtype=np.float64) for s in self.sets],
+                                 [np.asarray(s["b"], dtype=np.float64) for s in self.sets],
+                                 projections=[self._primitive(s) for s in self.sets], rho=self.rho,
+                                 max_iter=self.max_iter, threshold=self.threshold)
+        y[:, c0:c0 + d] = blk
+        return y.reshape(np.shape(flat))
+
+
+def keepout_rectangles(dim, centres, sizes, angle, margin=0.5, upper=1e5, rho=10.0, max_iter=15, threshold=1e-3):
+    """State constraint of notebooks/Car/Iterative LQR with state constraints.ipynb cell 18: stay outside rotated
+    rectangles (width, length = sizes[i] + margin, rotated by `angle`, centred at centres[i]) in the first two
+    coordinates of a `dim`-vector."""
+    Rm = np.array([[np.cos(angle), -np.sin(angle)], [np.sin(angle), np.cos(angle)]])
+    sets = []
+    for c, a in zip(np.asarray(centres, dtype=np.float64), np.asarray(sizes, dtype=np.float64)):
+        a_safe = a + margin
+        W = np.diag(a_safe[0] / a_safe) @ Rm.T
+        par = np.concatenate([[2, a_safe[0] / 2, upper], c, W.ravel(), np.linalg.inv(W).ravel()])
+        sets.append(dict(kind=SET_SQUARE, dim=dim, A=np.eye(dim), b=np.zeros(dim), par=par))
+    return ConvexSets(dim, (0, dim), sets, rho=rho, max_iter=max_iter, threshold=threshold)
+
+
 def identify_box(project, size, rng_seed=0):
     """Recognise an opaque `project(flat_vector)` callback as a box and return the equivalent `Box`, else None.
 

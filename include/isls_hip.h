@@ -66,6 +66,7 @@ extern "C" {
 /* projections (z-step of ADMM) */
 #define ISLS_PROJ_NONE 0
 #define ISLS_PROJ_BOX 1        /* np.clip(x, lo, hi)   isls/projections.py:7-11 ; bounds per (t, dim), +-inf = free */
+#define ISLS_PROJ_SETS 2       /* project_set_convex over the time steps, isls/projections.py:289-374 (isls_admm_args) */
 
 typedef struct isls_view {
     const void *p;
@@ -213,9 +214,54 @@ int isls_rollout_ls_f64(const isls_rollout_args *a, void *stream);
 int isls_rollout_ls_f32(const isls_rollout_args *a, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row-wise projections onto an intersection of sets.
+ * Replaces isls/projections.py: project_bound (7-11), project_soc_unit_batch (140-162),
+ * project_square_batch (256-266, with the affine keep-out transform of the car notebook) and
+ * project_set_convex (289-374): the inner ADMM
+ *   x = (I + rho sum A_i'A_i)^-1 (x0 + rho sum A_i'(z_i - b_i - l_i)),  z_i = P_i(A_i x + b_i + l_i),
+ *   l_i += A_i x + b_i - z_i
+ * run for every row of a problem at once and stopped for all rows of that problem together (max-norm
+ * residuals below `threshold`, or both relative changes below 1e-5), like one call of the reference.
+ * P problems x R rows (<= 1024) of dimension d (<= ISLS_MAX_ROW_DIM); rows are addressed through
+ * (sp, sr) element strides so that a coordinate block of a [B,N,n] state array can be projected in place.
+ * nsets == 1 with sets[0].A == NULL applies the primitive directly (no iteration, dim == d).
+ * ------------------------------------------------------------------------------------------- */
+#define ISLS_MAX_ROW_DIM 4
+#define ISLS_MAX_SET_DIM 5
+#define ISLS_MAX_SETS 4
+#define ISLS_SET_BOX 1       /* par: lo[dim], hi[dim]                                                  */
+#define ISLS_SET_SOC_UNIT 2  /* (z, t) = first dim-1 entries, last entry; no parameters                */
+#define ISLS_SET_SQUARE 3    /* par: q, l, u, c[q], W[q*q], Winv[q*q]: l <= ||W(y[:q]-c)||_inf <= u    */
+
+typedef struct isls_cset {
+    int32_t kind, dim;          /* primitive and dimension of A y + b                               */
+    const void *A;              /* [dim, d] row-major; NULL only for the direct form                */
+    const void *b;              /* [dim]                                                            */
+    const void *par;            /* primitive parameters                                             */
+    int64_t A_sp, b_sp, par_sp; /* element strides between problems (0 = shared by all problems)    */
+} isls_cset;
+
+typedef struct isls_project_args {
+    int32_t P, R, d, nsets;
+    int32_t max_iter;
+    int32_t _pad;
+    double rho, threshold;
+    isls_cset sets[ISLS_MAX_SETS];
+    const void *y_in;           /* rows y_in[p*in_sp + r*in_sr + 0..d)   */
+    int64_t in_sp, in_sr;
+    void *y_out;                /* may alias y_in                          */
+    int64_t out_sp, out_sr;
+    int32_t *iters;             /* [P] nullable: inner iterations run      */
+    const int32_t *active;      /* [P] nullable                            */
+} isls_project_args;
+
+int isls_project_rows_f64(const isls_project_args *a, void *stream);
+int isls_project_rows_f32(const isls_project_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * ADMM z/dual update with projection, residuals and the two stop rules.
  * Replaces the body of ADMM() after the x-step (isls/admm.py:43-85) with project_x/project_u given
- * as descriptors (box: isls/projections.py:7-11):
+ * as descriptors (box: isls/projections.py:7-11; ISLS_PROJ_SETS: project_set_convex, 289-374):
  *   z_prev = z ; z = Proj(relax*x + (1-relax)*z + lmb) ; r = x - z ; lmb += r
  *   prim = |r_x| + |r_u| ; dual = |z_x - z_prev_x| + |z_u - z_prev_u|        (unscaled 2-norms)
  *   stop  if prim<tol_abs and dual<tol_abs, else if both relative changes (vs res_prev, +1e-30) < tol_rel
@@ -234,6 +280,13 @@ typedef struct isls_admm_args {
     void *res, *res_prev;
     int32_t *active;
     int32_t *iters;            /* [B] nullable: incremented for every trajectory updated by this call */
+    /* ISLS_PROJ_SETS: the z block is project_set_convex (isls_project_rows) over the N rows (time steps) of
+     * the coordinate block [col0, col0+d) of relax*x + (1-relax)*z + lmb, the other coordinates pass through
+     * (the state constraint of notebooks/Car/Iterative LQR with state constraints.ipynb cell 18).  Of the
+     * descriptor only d, nsets, sets, rho, max_iter, threshold are used. */
+    const isls_project_args *x_sets, *u_sets;
+    int32_t x_col0, u_col0;
+    void *x_work, *u_work;     /* [B,N,n] / [B,N,m] caller-owned scratch (argument of the projection) */
 } isls_admm_args;
 
 int isls_admm_update_f64(const isls_admm_args *a, void *stream);

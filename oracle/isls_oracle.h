@@ -15,6 +15,7 @@ extern "C" {
     int oracle_accept_step_##sfx(const isls_accept_args *a);                                          \
     int oracle_reduce_convergence_##sfx(int32_t B, const void *cost, const void *res,                 \
                                         const int32_t *active, const int32_t *status, void *out5);    \
+    int oracle_project_rows_##sfx(const isls_project_args *a);                                        \
     int oracle_ilqr_admm_outer_##sfx(const isls_outer_args *a);
 ORACLE_DECL(f64)
 ORACLE_DECL(f32)

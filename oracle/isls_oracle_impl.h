@@ -418,8 +418,10 @@ int FN(oracle_rollout_ls)(const isls_rollout_args *a)
 /* ---------------------------------------------------------------------------------------------
  * ADMM update.  isls/admm.py:43-85, box projection isls/projections.py:7-11.
  * ------------------------------------------------------------------------------------------- */
+int FN(oracle_project_rows)(const isls_project_args *a);
+
 static void FN(admm_block)(int N, int d, int proj, REAL relax, const REAL *x, REAL *z, REAL *l,
-                           const isls_view *lo, const isls_view *hi, int b, REAL *prim2, REAL *dual2)
+                           const isls_view *lo, const isls_view *hi, const REAL *work, int b, REAL *prim2, REAL *dual2)
 {
     REAL p2 = 0, d2 = 0;
     for (int t = 0; t < N; ++t) {
@@ -431,6 +433,7 @@ static void FN(admm_block)(int N, int d, int proj, REAL relax, const REAL *x, RE
             REAL arg = zz + l[e];
             REAL zn = arg;
             if (proj == ISLS_PROJ_BOX) { zn = arg < lo_t[i] ? lo_t[i] : arg; zn = zn > hi_t[i] ? hi_t[i] : zn; } /* np.clip */
+            else if (proj == ISLS_PROJ_SETS) zn = work[e];  /* project_set_convex of the argument, done for all rows before */
             REAL r = x[e] - zn;                            /* admm.py:51 */
             l[e] += r;                                     /* admm.py:52 */
             z[e] = zn;
@@ -445,18 +448,38 @@ int FN(oracle_admm_update)(const isls_admm_args *a)
 {
     const int B = a->B, N = a->N, n = a->n, m = a->m;
     if (B < 0 || N < 1 || n < 1 || m < 1) return ISLS_ERR_ARG;
+    for (int blk = 0; blk < 2; ++blk) {   /* ISLS_PROJ_SETS: argument -> work, project_set_convex over the time steps */
+        const int isx = blk == 0, d = isx ? n : m, col0 = isx ? a->x_col0 : a->u_col0;
+        if (!(isx ? a->zx : a->zu) || (isx ? a->proj_x : a->proj_u) != ISLS_PROJ_SETS) continue;
+        const isls_project_args *ps = isx ? a->x_sets : a->u_sets;
+        REAL *work = (REAL *)(isx ? a->x_work : a->u_work);
+        if (!ps || !work) return ISLS_ERR_ARG;
+        const REAL *x = (const REAL *)(isx ? a->xx : a->xu), *z = (const REAL *)(isx ? a->zx : a->zu), *l = (const REAL *)(isx ? a->lx : a->lu);
+        for (int b = 0; b < B; ++b) {
+            if (a->active && !a->active[b]) continue;
+            for (int64_t e = (int64_t)b * N * d; e < (int64_t)(b + 1) * N * d; ++e)
+                work[e] = ((REAL)a->relax * x[e] + (1 - (REAL)a->relax) * z[e]) + l[e];
+        }
+        isls_project_args pr = *ps;
+        pr.P = B; pr.R = N; pr.y_in = work + col0; pr.y_out = work + col0;
+        pr.in_sp = pr.out_sp = (int64_t)N * d; pr.in_sr = pr.out_sr = d; pr.iters = 0; pr.active = a->active;
+        int rc = FN(oracle_project_rows)(&pr);
+        if (rc != ISLS_OK) return rc;
+    }
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b) {
         if (a->active && !a->active[b]) continue;
         REAL prim = 0, dual = 0, p2, d2;
         if (a->zx) {
             FN(admm_block)(N, n, a->proj_x, (REAL)a->relax, (const REAL *)a->xx + (int64_t)b * N * n,
-                           (REAL *)a->zx + (int64_t)b * N * n, (REAL *)a->lx + (int64_t)b * N * n, &a->x_lo, &a->x_hi, b, &p2, &d2);
+                           (REAL *)a->zx + (int64_t)b * N * n, (REAL *)a->lx + (int64_t)b * N * n, &a->x_lo, &a->x_hi,
+                           a->proj_x == ISLS_PROJ_SETS ? (const REAL *)a->x_work + (int64_t)b * N * n : 0, b, &p2, &d2);
             prim += SQRT(p2); dual += SQRT(d2);
         }
         if (a->zu) {
             FN(admm_block)(N, m, a->proj_u, (REAL)a->relax, (const REAL *)a->xu + (int64_t)b * N * m,
-                           (REAL *)a->zu + (int64_t)b * N * m, (REAL *)a->lu + (int64_t)b * N * m, &a->u_lo, &a->u_hi, b, &p2, &d2);
+                           (REAL *)a->zu + (int64_t)b * N * m, (REAL *)a->lu + (int64_t)b * N * m, &a->u_lo, &a->u_hi,
+                           a->proj_u == ISLS_PROJ_SETS ? (const REAL *)a->u_work + (int64_t)b * N * m : 0, b, &p2, &d2);
             prim += SQRT(p2); dual += SQRT(d2);
         }
         REAL *res = (REAL *)a->res + (int64_t)b * 2;
@@ -631,6 +654,163 @@ int FN(oracle_reduce_convergence)(int32_t B, const void *cost, const void *res, 
     }
     o[0] = cs; o[1] = pm; o[2] = dm; o[3] = na; o[4] = nf;
     return ISLS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Row-wise projections: isls/projections.py 7-11 (project_bound), 140-162 (project_soc_unit_batch),
+ * 256-266 (project_square_batch; affine keep-out form of the car notebook, cell 18) and 289-374
+ * (project_set_convex, all rows of one problem stopped together).
+ * ------------------------------------------------------------------------------------------- */
+static REAL FN(npsign)(REAL x) { return x > 0 ? (REAL)1 : (x < 0 ? (REAL)-1 : (REAL)0); }
+
+static void FN(primitive)(int kind, int dim, const REAL *par, REAL *v)
+{
+    if (kind == ISLS_SET_BOX) {
+        for (int i = 0; i < dim; ++i) {
+            REAL a = v[i] < par[i] ? par[i] : v[i];
+            v[i] = a > par[dim + i] ? par[dim + i] : a;
+        }
+    } else if (kind == ISLS_SET_SOC_UNIT) {
+        REAL ss = 0, t = v[dim - 1];
+        for (int i = 0; i < dim - 1; ++i) ss += v[i] * v[i];
+        REAL zn = SQRT(ss);
+        int cond1 = (zn <= -t) || (t < 0), cond2 = (zn > t) || (zn > -t), cond3 = zn <= t;
+        REAL tmp = (zn + t) / 2, o[ISLS_MAX_SET_DIM];
+        for (int i = 0; i < dim; ++i) o[i] = v[i];
+        if (cond2) { for (int i = 0; i < dim - 1; ++i) o[i] = tmp * v[i] / (zn + (REAL)1e-30); o[dim - 1] = tmp; }
+        if (cond1) for (int i = 0; i < dim; ++i) o[i] = 0;
+        if (cond3) for (int i = 0; i < dim; ++i) o[i] = v[i];
+        for (int i = 0; i < dim; ++i) v[i] = o[i];
+    } else if (kind == ISLS_SET_SQUARE) {
+        int q = (int)par[0];
+        REAL l = par[1], u = par[2];
+        const REAL *c = par + 3, *W = c + q, *Wi = W + q * q;
+        REAL y[ISLS_MAX_SET_DIM], w[ISLS_MAX_SET_DIM];
+        for (int i = 0; i < q; ++i) y[i] = v[i] - c[i];
+        for (int i = 0; i < q; ++i) { REAL acc = 0; for (int j = 0; j < q; ++j) acc += y[j] * W[i * q + j]; w[i] = acc; }
+        int jm = 0;
+        REAL am = -1;
+        for (int i = 0; i < q; ++i) { REAL a = FABS(w[i]); if (a > am) { am = a; jm = i; } }
+        if (am < l) w[jm] = l * FN(npsign)(w[jm]);
+        for (int i = 0; i < q; ++i) { REAL o = w[i] > u ? u : w[i]; w[i] = o < -u ? -u : o; }
+        for (int i = 0; i < q; ++i) { REAL acc = 0; for (int j = 0; j < q; ++j) acc += w[j] * Wi[i * q + j]; v[i] = acc + c[i]; }
+    }
+}
+
+int FN(oracle_project_rows)(const isls_project_args *a)
+{
+    const int P = a->P, R = a->R, d = a->d, ns = a->nsets;
+    if (P < 0 || R < 1 || d < 1 || d > ISLS_MAX_ROW_DIM || ns < 1 || ns > ISLS_MAX_SETS || !a->y_in || !a->y_out) return ISLS_ERR_ARG;
+    const int direct = ns == 1 && a->sets[0].A == 0;
+    const REAL rho = (REAL)a->rho, thr = (REAL)a->threshold;
+    int rc = ISLS_OK;
+#pragma omp parallel for schedule(dynamic)
+    for (int p = 0; p < P; ++p) {
+        if (a->active && !a->active[p]) continue;
+        const REAL *yin = (const REAL *)a->y_in + (int64_t)p * a->in_sp;
+        REAL *yout = (REAL *)a->y_out + (int64_t)p * a->out_sp;
+        if (direct) {
+            const REAL *par = a->sets[0].par ? (const REAL *)a->sets[0].par + (int64_t)p * a->sets[0].par_sp : 0;
+            for (int r = 0; r < R; ++r) {
+                REAL v[ISLS_MAX_SET_DIM];
+                for (int j = 0; j < d; ++j) v[j] = yin[(int64_t)r * a->in_sr + j];
+                FN(primitive)(a->sets[0].kind, d, par, v);
+                for (int j = 0; j < d; ++j) yout[(int64_t)r * a->out_sr + j] = v[j];
+            }
+            if (a->iters) a->iters[p] = 0;
+            continue;
+        }
+        const REAL *A[ISLS_MAX_SETS], *b[ISLS_MAX_SETS], *par[ISLS_MAX_SETS];
+        int dim[ISLS_MAX_SETS];
+        for (int s = 0; s < ns; ++s) {
+            A[s] = (const REAL *)a->sets[s].A + (int64_t)p * a->sets[s].A_sp;
+            b[s] = (const REAL *)a->sets[s].b + (int64_t)p * a->sets[s].b_sp;
+            par[s] = a->sets[s].par ? (const REAL *)a->sets[s].par + (int64_t)p * a->sets[s].par_sp : 0;
+            dim[s] = a->sets[s].dim;
+        }
+        /* l_side_inv = inv(I + rho sum A'A)  (np.linalg.inv: LU with partial pivoting) */
+        REAL M[ISLS_MAX_ROW_DIM * ISLS_MAX_ROW_DIM], Linv[ISLS_MAX_ROW_DIM * ISLS_MAX_ROW_DIM];
+        for (int i = 0; i < d * d; ++i) M[i] = 0;
+        for (int s = 0; s < ns; ++s)
+            for (int j = 0; j < d; ++j)
+                for (int k = 0; k < d; ++k) {
+                    REAL acc = 0;
+                    for (int i = 0; i < dim[s]; ++i) acc += A[s][i * d + j] * A[s][i * d + k];
+                    M[j * d + k] += acc;
+                }
+        for (int j = 0; j < d; ++j)
+            for (int k = 0; k < d; ++k) M[j * d + k] = (j == k ? (REAL)1 : (REAL)0) + rho * M[j * d + k];
+        if (FN(inv_lu)(M, Linv, d)) { rc = ISLS_ERR_ARG; continue; }
+        const int SD = ISLS_MAX_SETS * ISLS_MAX_SET_DIM;
+        REAL *x = (REAL *)malloc(sizeof(REAL) * (size_t)R * (ISLS_MAX_ROW_DIM + 2 * SD));
+        REAL *z = x + (size_t)R * ISLS_MAX_ROW_DIM, *lm = z + (size_t)R * SD;
+        for (int r = 0; r < R; ++r) {
+            const REAL *x0 = yin + (int64_t)r * a->in_sr;
+            for (int j = 0; j < d; ++j) x[r * ISLS_MAX_ROW_DIM + j] = x0[j];
+            for (int s = 0; s < ns; ++s)
+                for (int i = 0; i < dim[s]; ++i) {
+                    REAL acc = 0;
+                    for (int j = 0; j < d; ++j) acc += A[s][i * d + j] * x0[j];
+                    z[r * SD + s * ISLS_MAX_SET_DIM + i] = acc + b[s][i];
+                    lm[r * SD + s * ISLS_MAX_SET_DIM + i] = 0;
+                }
+        }
+        REAL prim_g = (REAL)1e5, dual_g = (REAL)1e5;
+        int it = 0;
+        for (int j = 0; j < a->max_iter; ++j) {
+            ++it;
+            REAL prev_p = prim_g, prev_d = dual_g, pm = 0, dm = 0;
+            for (int r = 0; r < R; ++r) {
+                const REAL *x0 = yin + (int64_t)r * a->in_sr;
+                REAL *xr = x + r * ISLS_MAX_ROW_DIM, *zr = z + r * SD, *lr = lm + r * SD;
+                REAL rs[ISLS_MAX_ROW_DIM];
+                for (int k = 0; k < d; ++k) rs[k] = 0;
+                for (int s = 0; s < ns; ++s)
+                    for (int i = 0; i < dim[s]; ++i) {
+                        REAL w = (-b[s][i] + zr[s * ISLS_MAX_SET_DIM + i]) - lr[s * ISLS_MAX_SET_DIM + i];
+                        for (int k = 0; k < d; ++k) rs[k] += A[s][i * d + k] * w;
+                    }
+                for (int i = 0; i < d; ++i) {
+                    REAL acc = 0;
+                    for (int k = 0; k < d; ++k) acc += Linv[i * d + k] * (x0[k] + rho * rs[k]);
+                    xr[i] = acc;
+                }
+                for (int s = 0; s < ns; ++s) {
+                    REAL axb[ISLS_MAX_SET_DIM], v[ISLS_MAX_SET_DIM], dres[ISLS_MAX_ROW_DIM], pn = 0, dn = 0;
+                    for (int i = 0; i < dim[s]; ++i) {
+                        REAL acc = 0;
+                        for (int k = 0; k < d; ++k) acc += A[s][i * d + k] * xr[k];
+                        axb[i] = acc + b[s][i];
+                        v[i] = axb[i] + lr[s * ISLS_MAX_SET_DIM + i];
+                    }
+                    FN(primitive)(a->sets[s].kind, dim[s], par[s], v);
+                    for (int k = 0; k < d; ++k) dres[k] = 0;
+                    for (int i = 0; i < dim[s]; ++i) {
+                        REAL pr = axb[i] - v[i], dz = v[i] - zr[s * ISLS_MAX_SET_DIM + i];
+                        for (int k = 0; k < d; ++k) dres[k] += A[s][i * d + k] * dz;
+                        lr[s * ISLS_MAX_SET_DIM + i] += pr;
+                        zr[s * ISLS_MAX_SET_DIM + i] = v[i];
+                        pn += pr * pr;
+                    }
+                    for (int k = 0; k < d; ++k) dn += (rho * dres[k]) * (rho * dres[k]);
+                    pn = SQRT(pn); dn = SQRT(dn);
+                    if (pn > pm) pm = pn;
+                    if (dn > dm) dm = dn;
+                }
+            }
+            prim_g = pm; dual_g = dm;
+            if (prim_g < thr && dual_g < thr) break;
+            if (j != a->max_iter - 1) {
+                REAL pc = FABS(prev_p - prim_g) / (prev_p + (REAL)1e-30), dc = FABS(prev_d - dual_g) / (prev_d + (REAL)1e-30);
+                if (pc < (REAL)1e-5 && dc < (REAL)1e-5) break;
+            }
+        }
+        for (int r = 0; r < R; ++r)
+            for (int j = 0; j < d; ++j) yout[(int64_t)r * a->out_sr + j] = x[r * ISLS_MAX_ROW_DIM + j];
+        if (a->iters) a->iters[p] = it;
+        free(x);
+    }
+    return rc;
 }
 
 /* One outer iteration: gain -> J x [ff -> rollout -> update]  (SURVEY 3.3 / 8d metric definition). */

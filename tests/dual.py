@@ -47,6 +47,12 @@ class DualKernels:
         getattr(self.oracle, name)(*args, **kw)
         if name == "riccati_ff" and self.ff_nseg > 1:
             dkw = dict(dkw, seg=self._prepare_segments(dargs, dkw))
+        for blk in ("x", "u"):                                 # set descriptors hold pointers: rebuild them on the device
+            if dkw.get(blk + "_sets") is not None:
+                spec, work = dkw[blk + "_sets"]._spec, dkw[blk + "_work"]
+                dsets = [{k: self._to_dev(v) for k, v in st.items()} for st in spec["sets"]]
+                dkw[blk + "_sets"] = capi.Kernels.project_args(work, work, dsets, rho=spec["rho"], max_iter=spec["max_iter"],
+                                                               threshold=spec["threshold"], cols=spec["cols"])
         getattr(self.hip, name)(*dargs, **dkw)
         torch.cuda.synchronize()
         self.calls += 1

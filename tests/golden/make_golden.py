@@ -467,6 +467,38 @@ def gen_arm():
     save("g4_arm3r.npz", **out)
 
 
+def ref_keepout_projection(N, d):
+    """project_state of notebooks/Car/Iterative LQR with state constraints.ipynb cell 18 (reference functions only)."""
+    xs_ = np.array([[-7.0, -3.0], [-3.0, -7.0]])
+    a_ = np.array([[2.0, 1.0], [2.0, 1.0]])
+    a_safe = a_ + 0.5
+    Ws = np.stack([np.diag(a_safe[0, 0] / a_safe[0]), np.diag(a_safe[1, 0] / a_safe[1])])
+    alpha = -np.pi / 4
+    Rm = np.array([[np.cos(alpha), -np.sin(alpha)], [np.sin(alpha), np.cos(alpha)]])
+    Ws = Ws @ Rm.T
+    Ws_inv = np.linalg.inv(Ws)
+    upper_sq, lower_sq = 1e5, a_safe[:, 0] / 2
+
+    def make_function(i):
+        def f(y):
+            y_ = y.reshape(N, d).copy()
+            z = y_[:, :2] - xs_[i][None]
+            z_projected = refproj.project_square_batch(z @ Ws[i].T, lower_sq[i], upper_sq)
+            y_[:, :2] = z_projected @ Ws_inv[i].T + xs_[i][None]
+            return y_
+        return f
+
+    projections = [make_function(i) for i in range(2)]
+    As, bs = [np.eye(d)] * 2, [np.zeros(d)] * 2
+
+    def project_state(x):
+        x_ = x.reshape(N, d).copy()
+        return refproj.project_set_convex(x_, As, bs, projections, rho=1e1, max_iter=15, verbose=0, threshold=1e-3).flatten()
+    rho_x = np.zeros((N, d, d))
+    rho_x[:, :2, :2] = np.eye(2) * 1e-1
+    return project_state, rho_x
+
+
 def gen_car():
     out = {}
     cfg = P.config4(batch=2, N=200, seed=0)
@@ -501,6 +533,18 @@ def gen_car():
     print("car O2 sensitivity to a 1e-15 input perturbation:", sens)
     out["o2_sens_keys"] = np.array(list(sens.keys()))
     out["o2_sens"] = np.array(list(sens.values()))
+    # O2 with the notebook's STATE constraint (state constraints.ipynb cells 18-20): two rotated keep-out rectangles
+    # intersected by project_set_convex (rho=10, 15 iterations, 1e-3), rho_x = 0.1 on the two positions, no control
+    # constraint; the closures below are the notebook's cell 18 written with the reference's own functions
+    project_state, rho_k = ref_keepout_projection(N, n)
+    traces = []
+    for b in range(2):
+        obj, get_AB = make_ref_isls(cfg, b)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, project_state, None, rho_k, None, max_iter=3, L=L, J=10, relax=1.0, tol=0.0, trace=tr)
+        traces.append(tr)
+    pack_trace("o2k", traces, n, m, N, 10, out)
+
     # pin: the notebook's own initial cost (state constraints.ipynb:214), x0=[0,-2,pi/2,0], u0 = 0
     c = dict(cfg)
     c["x0"] = np.array([[0.0, -2.0, np.pi / 2, 0.0]])
@@ -542,6 +586,10 @@ def gen_projections():
     out["setcvx_A0"], out["setcvx_A1"], out["setcvx_b0"], out["setcvx_b1"] = A_[0], A_[1], b_[0], b_[1]
     out["setcvx_out"] = refproj.project_set_convex(y.copy(), A_, b_, projections=[refproj.project_soc_unit] * 2,
                                                    rho=1e1, max_iter=100, threshold=1e-3)
+    # keep-out rectangles of the car notebook on [N,4] state rows
+    proj_state, _ = ref_keepout_projection(200, 4)
+    xk = rng.standard_normal((200, 4)) * np.array([3.0, 3.0, 1.0, 1.0]) + np.array([-5.0, -5.0, 0.0, 0.0])
+    out["keepout_in"], out["keepout_out"] = xk, proj_state(xk.reshape(-1).copy()).reshape(200, 4)
     save("g6_projections.npz", **out)
 
 

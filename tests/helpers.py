@@ -53,8 +53,10 @@ class OracleDriver:
     """Outer loop over oracle kernels (numpy).  Records a trace shaped like tests/golden 'o2_*'."""
 
     def __init__(self, kern, pa, rho_x=None, rho_u=None, project_x=False, project_u=True, relax=1.0,
-                 dtype=np.float64):
+                 dtype=np.float64, x_sets=None):
+        """x_sets: an isls.projections.ConvexSets on the state rows (ISLS_PROJ_SETS) instead of the box pa['x_lo/hi']."""
         self.kern, self.pa, self.dtype = kern, pa, dtype
+        self.x_sets = x_sets
         B, N, n, m = pa["B"], pa["N"], pa["n"], pa["m"]
         self.B, self.N, self.n, self.m = B, N, n, m
         self.Qr = rho_to_weights(rho_x, N, n, dtype) if project_x else None
@@ -110,8 +112,28 @@ class OracleDriver:
                              wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
                              cost_cur=self.cost, flags=flags, status=self.status, active=self.admm_active)
 
+    def set_args(self):
+        """(x_sets descriptor, x_col0, x_work) keyword arguments of admm_args for the ConvexSets state constraint."""
+        if self.x_sets is None:
+            return {}
+        if getattr(self, "_xs", None) is None:
+            cs = self.x_sets
+            self.x_work = np.zeros((self.B, self.N, self.n), dtype=self.dtype)
+            sets = [{k: (np.ascontiguousarray(v, dtype=self.dtype) if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+                    for st in cs.sets]
+            self._xs = capi.Kernels.project_args(self.x_work, self.x_work, sets, rho=cs.rho, max_iter=cs.max_iter,
+                                                 threshold=cs.threshold, cols=cs.cols)
+        return dict(x_sets=self._xs, x_col0=self.x_sets.cols[0], x_work=self.x_work)
+
     def update(self, tol):
         pa = self.pa
+        if self.x_sets is not None:
+            self.kern.admm_update(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
+                                  u_lo=pa["u_lo"] if self.zu is not None else None,
+                                  u_hi=pa["u_hi"] if self.zu is not None else None,
+                                  relax=self.relax, tol_abs=tol, tol_rel=tol, res_prev=self.res_prev,
+                                  active=self.admm_active, **self.set_args())
+            return
         self.kern.admm_update(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
                               x_lo=pa.get("x_lo") if self.zx is not None else None,
                               x_hi=pa.get("x_hi") if self.zx is not None else None,

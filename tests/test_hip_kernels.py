@@ -186,3 +186,82 @@ def test_fp32_kernels(dual):
     d = OracleDriver(dk, pa, rho_u=cfg["rho_u"], relax=cfg["relax"], dtype=np.float32)
     d.run(2, 20, 3, 0.0)
     _report(dk)
+
+
+def test_car_state_constraint_kernels(dual):
+    """ISLS_PROJ_SETS inside the ADMM update (argument kernel + project_rows + update) on the car, kernel by kernel."""
+    import sys
+    pj = sys.modules["isls.projections"]
+    cfg = P.config4(batch=16, N=200, seed=0)
+    rho_x = np.zeros((200, 4, 4)); rho_x[:, :2, :2] = 0.1 * np.eye(2)
+    cs = pj.keepout_rectangles(4, [[-7.0, -3.0], [-3.0, -7.0]], [[2.0, 1.0], [2.0, 1.0]], -np.pi / 4)
+    dk = dual(ff_nseg=4)
+    d = OracleDriver(dk, problem_arrays(cfg, range(5)), rho_x=rho_x, project_x=True, project_u=False, x_sets=cs)
+    d.run(2, 20, 4, 0.0)
+    _report(dk)
+
+
+def _car_keepout_sets(dtype=np.float64):
+    """The two rotated keep-out rectangles of notebooks/Car/Iterative LQR with state constraints.ipynb cell 18 as
+    ISLS_SET_SQUARE parameter blocks acting on the position block of a 4-vector (A = I4, b = 0)."""
+    a_safe = np.array([[2.5, 1.5], [2.5, 1.5]])
+    al = -np.pi / 4
+    Rm = np.array([[np.cos(al), -np.sin(al)], [np.sin(al), np.cos(al)]])
+    centres = np.array([[-7.0, -3.0], [-3.0, -7.0]])
+    sets = []
+    for i in range(2):
+        W = np.diag(a_safe[i, 0] / a_safe[i]) @ Rm.T
+        par = np.concatenate([[2, a_safe[i, 0] / 2, 1e5], centres[i], W.ravel(), np.linalg.inv(W).ravel()]).astype(dtype)
+        sets.append(dict(kind=capi.SET_SQUARE, dim=4, A=np.eye(4, dtype=dtype), b=np.zeros(4, dtype=dtype), par=par))
+    return sets
+
+
+def _dual_project(oracle, y, sets, **kw):
+    import torch
+    from dual import hip_kernels
+    hip = hip_kernels()
+    P = y.shape[0]
+    out_o, it_o = np.zeros_like(y), np.zeros(P, dtype=np.int32)
+    oracle.project_rows(y, out_o, sets, iters=it_o, **kw)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    dsets = [{k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in s.items()} for s in sets]
+    yd, od, itd = dev(y), dev(np.zeros_like(y)), dev(np.zeros(P, dtype=np.int32))
+    dkw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    hip.project_rows(yd, od, dsets, iters=itd, **dkw)
+    torch.cuda.synchronize()
+    return out_o, it_o, od.cpu().numpy(), itd.cpu().numpy()
+
+
+def test_projection_kernels(oracle, golden):
+    """isls_project_rows on the device against the oracle: direct primitives, the SOC chance-constraint rows with
+    per-problem operands, the car's keep-out rectangles on a coordinate block of strided rows, R > 64 rows."""
+    g = golden("g6_projections.npz")
+    rng = np.random.default_rng(7)
+    # direct primitives (bit-exact: same operations in the same order)
+    soc = np.ascontiguousarray(np.stack([g["soc_in"], 0.3 * g["soc_in"]]))
+    o, _, h, _ = _dual_project(oracle, soc, [dict(kind=capi.SET_SOC_UNIT, dim=4)])
+    assert np.max(np.abs(o - h)) < 1e-15
+    sq = rng.standard_normal((3, 130, 2)) * 2
+    par = np.concatenate([[2, 1.0, 2.5], [0.2, -0.1], np.eye(2).ravel(), np.eye(2).ravel()])
+    o, _, h, _ = _dual_project(oracle, sq, [dict(kind=capi.SET_SQUARE, dim=2, par=par)])
+    assert np.max(np.abs(o - h)) < 1e-15
+    # chance-constraint rows: two SOC images, A_i, b_i differ per problem (variance / bound per problem)
+    P, R = 9, 50
+    A0 = np.tile(g["setcvx_A0"][None], (P, 1, 1)) * (1 + 0.2 * rng.random((P, 1, 1)))
+    A1 = np.tile(g["setcvx_A1"][None], (P, 1, 1)) * (1 + 0.2 * rng.random((P, 1, 1)))
+    b0 = np.tile(g["setcvx_b0"][None], (P, 1)) * (1 + 0.3 * rng.random((P, 1)))
+    b1 = np.tile(g["setcvx_b1"][None], (P, 1)) * (1 + 0.3 * rng.random((P, 1)))
+    sets = [dict(kind=capi.SET_SOC_UNIT, dim=3, A=A0, b=b0), dict(kind=capi.SET_SOC_UNIT, dim=3, A=A1, b=b1)]
+    y = rng.standard_normal((P, R, 2)) * np.array([6.0, 30.0])
+    act = np.ones(P, dtype=np.int32); act[4] = 0
+    o, io, h, ih = _dual_project(oracle, y, sets, rho=10.0, max_iter=100, threshold=1e-3, active=act)
+    assert np.array_equal(io, ih) and np.max(np.abs(o - h)) < 1e-10 and np.all(h[4] == 0)
+    # keep-out rectangles on the position block of [B, N, 4] state rows, N = 200 rows per problem
+    sets = _car_keepout_sets()
+    x = rng.standard_normal((5, 200, 4)) * np.array([3.0, 3.0, 1.0, 1.0]) + np.array([-5.0, -5.0, 0, 0])
+    o, io, h, ih = _dual_project(oracle, x, sets, rho=10.0, max_iter=15, threshold=1e-3)
+    assert np.array_equal(io, ih) and np.max(np.abs(o - h)) < 1e-10
+    assert np.max(np.abs(o[..., 2:] - x[..., 2:])) < 1e-12                 # heading / speed untouched
+    # fp32
+    o, io, h, ih = _dual_project(oracle, x.astype(np.float32), _car_keepout_sets(np.float32), rho=10.0, max_iter=15, threshold=1e-3)
+    assert np.max(np.abs(o - h)) < 1e-4

@@ -198,6 +198,25 @@ def test_ilqr_admm_arm_and_car(golden):
         _check_final(s, g, "o2", [0, 1], 3, cfg["max_admm_iter"], _tols(g, "o2"))
 
 
+def test_ilqr_admm_car_keepout_state_constraint(golden):
+    """Config 4 with the notebook's state constraint (two rotated keep-out rectangles, project_set_convex) running
+    entirely on the device (ISLS_PROJ_SETS), against the reference's O2 trace; the same ConvexSets object passed as an
+    opaque callable takes the host route and must agree."""
+    import sys
+    pj = sys.modules["isls.projections"]
+    g = golden("g5_car.npz")
+    cfg = P.config4(batch=2, N=200, seed=0)
+    rho_x = np.zeros((200, 4, 4)); rho_x[:, :2, :2] = 0.1 * np.eye(2)
+    cs = pj.keepout_rectangles(4, [[-7.0, -3.0], [-3.0, -7.0]], [[2.0, 1.0], [2.0, 1.0]], -np.pi / 4)
+    s = make_isls(cfg, [0, 1])
+    s.ilqr_admm(project_x=cs, max_iter=3, max_line_search_iter=20, max_admm_iter=10, rho_x=rho_x, alpha=1.0, tol=0.0)
+    _check_final(s, g, "o2k", [0, 1], 3, 10, _tols(g, "o2k"))
+    h = make_isls(cfg, [0, 1])
+    h.ilqr_admm(project_x=lambda x: cs(x), max_iter=3, max_line_search_iter=20, max_admm_iter=10, rho_x=rho_x, alpha=1.0,
+                tol=0.0)
+    assert rel(s.x_nom, h.x_nom) < 1e-9 and rel(s.u_nom, h.u_nom) < 1e-9
+
+
 def test_ilqr_admm_host_projection_path(golden):
     """A projection the device has no kernel for goes through the caller's numpy function; on a box it must agree
     with the device path."""

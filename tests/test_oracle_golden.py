@@ -316,3 +316,70 @@ def test_car_o2(oracle, golden):
     d = OracleDriver(oracle, pa, rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
     tr = d.run(3, 20, cfg["max_admm_iter"], 0.0)
     check_trace(tr, g, "o2", 2)
+
+
+# ---- row-wise projections (isls_project_rows; isls/projections.py) -------------------------------------------------
+def _proj(kern, y, sets, **kw):
+    out = np.zeros_like(y)
+    it = np.zeros(y.shape[0], dtype=np.int32)
+    kern.project_rows(y, out, sets, iters=it, **kw)
+    return out, it
+
+
+def test_projection_primitives_match_reference(oracle, golden):
+    """oracle_project_rows direct forms == the reference's project_bound / project_soc_unit / project_square_batch."""
+    from isls import _capi as capi
+    g = golden("g6_projections.npz")
+    soc = np.ascontiguousarray(g["soc_in"][None])
+    out, _ = _proj(oracle, soc, [dict(kind=capi.SET_SOC_UNIT, dim=4)])
+    assert np.allclose(out[0], g["soc_out"], rtol=0, atol=1e-15)
+    sq = np.ascontiguousarray(g["square_in"][None])
+    par = np.concatenate([[2, 1.0, 2.5], [0, 0], np.eye(2).ravel(), np.eye(2).ravel()])
+    out, _ = _proj(oracle, sq, [dict(kind=capi.SET_SQUARE, dim=2, par=par)])
+    assert np.array_equal(out[0], g["square_out"])
+    bx = np.ascontiguousarray(g["bound_in"][None, :, :4])
+    par = np.concatenate([np.full(4, -1.5), np.full(4, 2.0)])
+    out, _ = _proj(oracle, bx, [dict(kind=capi.SET_BOX, dim=4, par=par)])
+    assert np.array_equal(out[0], g["bound_out"][:, :4])
+
+
+def test_project_set_convex_matches_reference(oracle, golden):
+    """the chance-constraint rows (two unit-SOC images): oracle == reference's project_set_convex."""
+    from isls import _capi as capi
+    g = golden("g6_projections.npz")
+    sets = [dict(kind=capi.SET_SOC_UNIT, dim=3, A=g["setcvx_A0"], b=g["setcvx_b0"]),
+            dict(kind=capi.SET_SOC_UNIT, dim=3, A=g["setcvx_A1"], b=g["setcvx_b1"])]
+    y = np.ascontiguousarray(g["setcvx_in"][None])
+    out, it = _proj(oracle, y, sets, rho=10.0, max_iter=100, threshold=1e-3)
+    assert np.allclose(out[0], g["setcvx_out"], rtol=0, atol=1e-12) and 1 <= it[0] <= 100
+    # two problems in one call stop independently: the second (rows already feasible) stops earlier
+    y2 = np.concatenate([y, 0.01 * y], 0)
+    out2, it2 = _proj(oracle, y2, sets, rho=10.0, max_iter=100, threshold=1e-3)
+    assert np.array_equal(out2[0], out[0]) and it2[0] == it[0] and it2[1] < it2[0]
+
+
+def test_keepout_rectangles_match_reference(oracle, golden):
+    """Car notebook cell 18 (two rotated keep-out rectangles through project_set_convex): the numpy ConvexSets and the
+    oracle's ISLS_SET_SQUARE sets reproduce the output of the reference's closures."""
+    import sys
+    pj = sys.modules["isls.projections"]
+    g = golden("g6_projections.npz")
+    cs = pj.keepout_rectangles(4, [[-7.0, -3.0], [-3.0, -7.0]], [[2.0, 1.0], [2.0, 1.0]], -np.pi / 4)
+    assert np.allclose(cs(g["keepout_in"].reshape(-1)).reshape(200, 4), g["keepout_out"], rtol=0, atol=1e-12)
+    out, it = _proj(oracle, np.ascontiguousarray(g["keepout_in"][None]), cs.sets, rho=cs.rho, max_iter=cs.max_iter,
+                    threshold=cs.threshold)
+    assert np.allclose(out[0], g["keepout_out"], rtol=0, atol=1e-12) and it[0] <= 15
+
+
+def test_car_o2_state_constraint(oracle, golden):
+    """Config 4 with the notebook's state constraint: ISLS_PROJ_SETS inside the ADMM update against the reference's
+    own O2 trace (project_state closure, rho_x = 0.1 on the positions, no control constraint)."""
+    import sys
+    pj = sys.modules["isls.projections"]
+    g = golden("g5_car.npz")
+    cfg = P.config4(batch=2, N=200, seed=0)
+    rho_x = np.zeros((200, 4, 4)); rho_x[:, :2, :2] = 0.1 * np.eye(2)
+    cs = pj.keepout_rectangles(4, [[-7.0, -3.0], [-3.0, -7.0]], [[2.0, 1.0], [2.0, 1.0]], -np.pi / 4)
+    d = OracleDriver(oracle, problem_arrays(cfg, [0, 1]), rho_x=rho_x, project_x=True, project_u=False, x_sets=cs)
+    tr = d.run(3, 20, 10, 0.0)
+    check_trace(tr, g, "o2k", 2)
