@@ -135,6 +135,24 @@ ISLS_API int isls_project_rows_f32(const isls_project_args *a, void *stream)
 {
     return a ? launch_project<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
+ISLS_API int isls_sls_admm_f64(const isls_sls_admm_args *a, void *stream)
+{
+    return a ? launch_sls_admm<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_sls_admm_f32(const isls_sls_admm_args *a, void *stream)
+{
+    return a ? launch_sls_admm<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_sls_closed_loop_f64(int32_t M, int32_t N, int32_t n, int32_t m, const void *A, const void *B, const void *K,
+                                      const void *k, const void *x0, void *x_log, void *u_log, void *stream)
+{
+    return launch_sls_closed_loop<double>(M, N, n, m, A, B, K, k, x0, x_log, u_log, (hipStream_t)stream);
+}
+ISLS_API int isls_sls_closed_loop_f32(int32_t M, int32_t N, int32_t n, int32_t m, const void *A, const void *B, const void *K,
+                                      const void *k, const void *x0, void *x_log, void *u_log, void *stream)
+{
+    return launch_sls_closed_loop<float>(M, N, n, m, A, B, K, k, x0, x_log, u_log, (hipStream_t)stream);
+}
 ISLS_API int isls_accept_step_f64(const isls_accept_args *a, void *stream)
 {
     return a ? launch_accept<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;

@@ -131,6 +131,14 @@ class ProjectArgs(C.Structure):
                 ("iters", C.c_void_p), ("active", C.c_void_p)]
 
 
+class SlsAdmmArgs(C.Structure):
+    _fields_ = [("P", C.c_int32), ("R", C.c_int32), ("D", C.c_int32), ("max_iter", C.c_int32),
+                ("alpha", C.c_double), ("tol", C.c_double), ("rel_tol", C.c_double),
+                ("Linv", C.c_void_p), ("r_side", C.c_void_p), ("rr", C.c_void_p),
+                ("proj", ProjectArgs),
+                ("x_u", C.c_void_p), ("z", C.c_void_p), ("lmb", C.c_void_p), ("logs", C.c_void_p), ("iters", C.c_void_p)]
+
+
 class OuterArgs(C.Structure):
     _fields_ = [("gain", GainArgs), ("ff", FfArgs), ("ro", RolloutArgs), ("admm", AdmmArgs),
                 ("J", C.c_int32), ("skip_gain", C.c_int32), ("log", C.c_void_p), ("outer_active", C.c_void_p)]
@@ -138,7 +146,7 @@ class OuterArgs(C.Structure):
 
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
-            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "expand_quadratic", "linearize",
+            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
            ["isls_ff_segments", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_pause",
             "isls_timing_read_ms"]
@@ -436,6 +444,33 @@ class Kernels:
     def project_rows(self, y_in, y_out, sets, stream=None, **kw):
         a = self.project_args(y_in, y_out, sets, **kw)
         return self._call("project_rows", _sfx(y_in), a, stream)
+
+    def sls_admm(self, Linv, r_side, rr, sets, x_u, alpha=1.0, tol=1e-3, max_iter=50, rho=1.0, inner_max_iter=200,
+                 threshold=1e-4, z=None, lmb=None, logs=None, iters=None, rel_tol=1e-2, stream=None):
+        """isls_sls_admm: Linv [R,R], r_side [P,R,D], rr [R], sets as in project_args (A [dim,D] or [P,dim,D] ...)."""
+        P, R, D = r_side.shape
+        _dense(Linv, (R, R), "Linv"), _dense(rr, (R,), "rr"), _dense(x_u, (P, R, D), "x_u")
+        pa = self.project_args(x_u, x_u, sets, rho=rho, max_iter=inner_max_iter, threshold=threshold)
+        a = SlsAdmmArgs(P=P, R=R, D=D, max_iter=int(max_iter), alpha=float(alpha), tol=float(tol), rel_tol=float(rel_tol),
+                        proj=pa)
+        a.Linv, a.r_side, a.rr = _ptr(Linv), _ptr(_dense(r_side, (P, R, D), "r_side")), _ptr(rr)
+        a.x_u, a.z, a.lmb = _ptr(x_u), _ptr(_dense(z, (P, R, D), "z")), _ptr(_dense(lmb, (P, R, D), "lmb"))
+        a.logs, a.iters = _ptr(_dense(logs, (P, int(max_iter), 2), "logs")), _ptr(iters)
+        a._keep = pa
+        return self._call("sls_admm", _sfx(r_side), a, stream)
+
+    def sls_closed_loop(self, A, Bm, K, k, x0, x_log, u_log, stream=None):
+        M, N, n = x_log.shape
+        m = u_log.shape[2]
+        _dense(A, (n, n), "A"), _dense(Bm, (n, m), "B"), _dense(K, (N * m, N * n), "K"), _dense(k, (N * m,), "k")
+        _dense(x0, (M, n), "x0"), _dense(u_log, (M, N, m), "u_log")
+        fn = getattr(self.lib, f"{self.prefix}sls_closed_loop_{_sfx(x_log)}")
+        fn.restype = C.c_int
+        args = [C.c_int32(M), C.c_int32(N), C.c_int32(n), C.c_int32(m)] + [C.c_void_p(_ptr(t)) for t in (A, Bm, K, k, x0, x_log, u_log)]
+        rc = fn(*args, C.c_void_p(stream or 0)) if self.with_stream else fn(*args)
+        if rc != OK:
+            raise IslsError(f"{self.prefix}sls_closed_loop -> {rc}")
+        return rc
 
     def riccati_ff_prepare(self, *args, stream=None, **kw):
         a = self.ff_prepare_args(*args, **kw)

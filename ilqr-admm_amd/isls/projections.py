@@ -97,6 +97,29 @@ def keepout_rectangles(dim, centres, sizes, angle, margin=0.5, upper=1e5, rho=10
     return ConvexSets(dim, (0, dim), sets, rho=rho, max_iter=max_iter, threshold=threshold)
 
 
+def chance_constraint_rows(p, upper, lower, var_x0, psi_inv, x0_pos=None, rho=10.0, max_iter=100, threshold=1e-3):
+    """Chance constraints lower <= u <= upper on the rows y = [d_u, phi_u] in R^(1+p) of the SLS variable, robust to
+    x0_pos ~ N(x0_pos, var_x0 I) with confidence Psi(psi_inv): two unit-SOC images
+        psi_inv |Sigma^(1/2) y| <= upper - mu'y ,  psi_inv |Sigma^(1/2) y| <= mu'y - lower ,  mu = [1, x0_pos]
+    (notebooks/Double integrator/LQR and SLS with control bounds.ipynb cell 15).  upper / lower / var_x0 / psi_inv may be
+    arrays of length B for B problems."""
+    up, lo, var, psi = (np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in (upper, lower, var_x0, psi_inv))
+    B = max(len(up), len(lo), len(var), len(psi))
+    up, lo, var, psi = (np.broadcast_to(v, (B,)) for v in (up, lo, var, psi))
+    mu = np.zeros(p + 1)
+    mu[0] = 1.0
+    if x0_pos is not None:
+        mu[1:] = x0_pos
+    A0, A1, b0, b1 = [], [], [], []
+    for b in range(B):
+        Au = np.diag(np.sqrt(np.concatenate([[0.0], np.full(p, var[b])])))
+        A0.append(np.concatenate([Au, (-mu / psi[b])[None]], 0)), A1.append(np.concatenate([Au, (mu / psi[b])[None]], 0))
+        b0.append(np.append(np.zeros(p + 1), up[b] / psi[b])), b1.append(np.append(np.zeros(p + 1), -lo[b] / psi[b]))
+    sq = (lambda a: np.ascontiguousarray(a[0])) if B == 1 else (lambda a: np.ascontiguousarray(np.stack(a)))
+    sets = [dict(kind=SET_SOC_UNIT, dim=p + 2, A=sq(A0), b=sq(b0)), dict(kind=SET_SOC_UNIT, dim=p + 2, A=sq(A1), b=sq(b1))]
+    return ConvexSets(p + 1, (0, p + 1), sets, rho=rho, max_iter=max_iter, threshold=threshold)
+
+
 def identify_box(project, size, rng_seed=0):
     """Recognise an opaque `project(flat_vector)` callback as a box and return the equivalent `Box`, else None.
 

@@ -8,16 +8,27 @@ their absolute-coordinate / explicit-inverse mode (`ISLS_SOLVE_INV`, `ISLS_RO_AB
     get_trajectory_dp               -> rollout_ls(ABSOLUTE)                                  (isls/sls_base.py:76-89)
     ADMM_LQT_DP                     -> gain once, then per iteration ff + rollout + admm_update (isls/sls.py:298-317)
 
-The batch-form / SLS (dense (N m)^2) solvers -- solve_batch, solve_sls, ADMM_LQT_Batch, ADMM_SLS, controller --
-are config 5 of BASELINE.json and not part of this round's hot path: they raise NotImplementedError.
+Config 5 of BASELINE.json (system level synthesis with chance constraints on the controls):
+
+    AB setter -> Sw, Su             transfer matrices, built on the host on first use        (isls/base.py:98-119)
+    solve_sls / compute_inverses    dense (N m)^2 set-up, numpy on the host, once per class of problems
+                                                                                            (isls/sls.py:205-233, base.py:29-50)
+    ADMM_SLS                        the ADMM loop itself runs on the device for all problems of the batch in one launch
+                                    (isls_sls_admm: x-step, project_set_convex over the rows, residuals, stop rules)
+                                                                                            (isls/sls.py:319-454)
+    controller / get_trajectory_sls K = Phi_u Phi_x^-1 (host set-up) and the closed-loop Monte-Carlo rollout (device)
+                                                                                            (isls/sls.py:235-242, sls_base.py:91-105)
+
+The remaining dense batch-form solvers (solve_batch, ADMM_LQT_Batch, replanning) raise NotImplementedError.
 """
 import numpy as np
 import torch
 
 from . import _capi as capi
+from . import sls_dense as dense
 from .base import Base
 from .models import LTI
-from .projections import Box
+from .projections import Box, ConvexSets
 
 
 class SLS(Base):
@@ -25,6 +36,8 @@ class SLS(Base):
         super().__init__(x_dim, u_dim, N, batch=batch, dtype=dtype, device=device)
         self.engine.solve_mode = capi.SOLVE_INV
         self._model = None
+        self._Sw = self._Su = None
+        self.l_side_invs = None
 
     # ---- dynamics -------------------------------------------------------------------------------------------
     @property
@@ -39,6 +52,8 @@ class SLS(Base):
         if self.A.ndim != 2:
             raise NotImplementedError("SLS is the LTI class of the reference (sls.py:139-140); use iSLS for time-varying A,B")
         self._model = LTI(self.A, self.B)
+        self._Sw = self._Su = None
+        self.l_side_invs = None
         e = self.engine
         e.set_model(self._model.model_id, self._model.params())
         e.A, e.Bm = e._t(self.A).reshape(1, 1, self.x_dim, self.x_dim), e._t(self.B).reshape(1, 1, self.x_dim, self.u_dim)
@@ -188,9 +203,103 @@ class SLS(Base):
                self._out(e.xu).reshape(-1) if B == 1 else e.xu.cpu().numpy().reshape(B, -1), self._out(e.K), self._out(e.k))
         return out + ((logs,) if log else ())
 
-    # ---- out of scope this round (config 5 / dense batch form) -----------------------------------------------------
-    def _config5(self, *a, **k):
-        raise NotImplementedError("dense batch-form / SLS solvers (config 5 of BASELINE.json) are not built in this round")
+    # ---- system level synthesis (config 5) ---------------------------------------------------------------------------
+    def _transfer(self):
+        """Sw, Su of the LTI model, built on first use (sls_dense.transfer_matrices)."""
+        if self._Sw is None:
+            assert self.A is not None, "Set the linear dynamics model by self.AB = [A,B] before calling this method."
+            self._Sw, self._Su = dense.transfer_matrices(self.A, self.B, self.N)
+        return self._Sw, self._Su
 
-    solve_batch = solve_sls = controller = ADMM_LQT_Batch = ADMM_SLS = _config5
-    initialize_replanning_procedure = replan_feedforward = get_trajectory_sls = get_trajectory_batch = _config5
+    Sw = property(lambda self: self._transfer()[0])
+    Su = property(lambda self: self._transfer()[1])
+
+    def _dense_cost(self):
+        return dense.dense_cost(self.zs, self.Qs, self.seq, self.u_std, self.N, self.x_dim, self.u_dim)
+
+    def compute_inverses(self, M):
+        return dense.compute_inverses(np.asarray(M, dtype=np.float64), self.u_dim, self.N)
+
+    def solve_sls(self, verbose=False):
+        """Unconstrained system level synthesis (isls/sls.py:205-233): feed-forward du [N m] (one per problem of the batch)
+        and the block-lower-triangular feedback map PHI_U [N m, N n]."""
+        assert self.Q is not None, "Set the quadratic cost model by self.set_cost_variables() before calling this method."
+        Sw, Su = self._transfer()
+        Q, R, xd = self._dense_cost()
+        PHI_U, du, self.l_side_invs = dense.solve_sls(Sw, Su, Q, R, xd, self.N, self.x_dim, self.u_dim, self.l_side_invs)
+        return PHI_U, du
+
+    def controller(self, PHI_U, du):
+        """K = Phi_u Phi_x^-1, k = (I - K Su) du (isls/sls.py:235-242); PHI_U / du may carry a leading batch axis."""
+        Sw, Su = self._transfer()
+        PHI_U, du = np.asarray(PHI_U, dtype=np.float64), np.asarray(du, dtype=np.float64)
+        if PHI_U.ndim == 3:
+            Ks, ks = zip(*(dense.controller(Sw, Su, P_, d_) for P_, d_ in zip(PHI_U, du)))
+            return np.stack(Ks), np.stack(ks)
+        return dense.controller(Sw, Su, PHI_U, du)
+
+    def ADMM_SLS(self, project_x=False, project_u=False, max_iter=5000, rho_x=0., rho_u=0., alpha=1., tol=1e-3,
+                 verbose=False, log=False):
+        """SLS-ADMM with robust (chance) constraints on the controls w.r.t. the initial position (isls/sls.py:319-454).
+        `project_u` is a `projections.ConvexSets` acting on the rows y = [d_u, phi_u] of the (N m) x (1 + n/2) variable
+        (e.g. `projections.chance_constraint_rows`); its A / b / par arrays may carry a leading batch axis for problems
+        that differ in bound or variance, and `zs` may be given per problem.  The set-up (transfer matrices, the (N m)^2
+        inverse) is host numpy, the ADMM loop of all problems is one device launch.  Returns du, phi_u[, logs]."""
+        if project_x:
+            raise NotImplementedError("ADMM_SLS with state constraints (project_x) is not built")
+        if not isinstance(project_u, ConvexSets):
+            raise NotImplementedError("ADMM_SLS runs its projection on the device: pass a projections.ConvexSets "
+                                      "(e.g. projections.chance_constraint_rows)")
+        e = self.engine
+        B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
+        p = n // 2
+        if project_u.dim != p + 1 or project_u.cols != (0, p + 1):
+            raise ValueError(f"project_u must act on rows of dimension 1 + x_dim/2 = {p + 1}")
+        self.l_side_invs = None
+        PHI_U, _ = self.solve_sls()
+        Sw, Su = self._transfer()
+        Q, R, xd = self._dense_cost()
+        rr = dense.rho_diagonal(rho_u, N, m)
+        l_side_inv, r_side = dense.admm_sls_setup(Sw, Su, Q, R, xd, rr, p, B)
+        dev = lambda a: e._t(np.ascontiguousarray(a))                                         # noqa: E731
+        sets = [{k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in st.items()} for st in project_u.sets]
+        x_u = torch.zeros(B, N * m, p + 1, dtype=e.dtype, device=e.device)
+        logs = torch.full((B, int(max_iter), 2), float("nan"), dtype=e.dtype, device=e.device)
+        iters = torch.zeros(B, dtype=torch.int32, device=e.device)
+        e.kern.sls_admm(dev(l_side_inv), dev(r_side), dev(rr), sets, x_u, alpha=alpha, tol=tol, max_iter=max_iter,
+                        rho=project_u.rho, inner_max_iter=project_u.max_iter, threshold=project_u.threshold, logs=logs,
+                        iters=iters, stream=torch.cuda.current_stream().cuda_stream)
+        xu = x_u.cpu().numpy().astype(np.float64)
+        self.sls_iters = iters.cpu().numpy()
+        du = xu[..., 0]
+        phi_u = np.concatenate([xu[..., 1:], np.broadcast_to(PHI_U[:, p:], (B,) + PHI_U[:, p:].shape)], axis=-1)
+        if B == 1:
+            du, phi_u = du[0], phi_u[0]
+        if not log:
+            return du, phi_u
+        lg = logs.cpu().numpy()
+        return du, phi_u, ([lg[0, j] for j in range(int(self.sls_iters[0]))] if B == 1 else lg)
+
+    def get_trajectory_sls(self, x0, K, k, noise_scale=0):
+        """Closed loop with the dense causal SLS controller: u_i = (K x_{0..i} + k)_i, x_{i+1} = A x_i + B u_i for a set
+        of initial states x0 [M, n] (isls/sls_base.py:91-105) -- the Monte-Carlo evaluation of the notebooks, one device
+        thread per initial state."""
+        if noise_scale:
+            raise NotImplementedError("process noise is drawn on the host in the reference; not built")
+        e = self.engine
+        x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
+        M, N, n, m = x0.shape[0], self.N, self.x_dim, self.u_dim
+        dev = lambda a: e._t(np.ascontiguousarray(a))                                         # noqa: E731
+        x_log = torch.zeros(M, N, n, dtype=e.dtype, device=e.device)
+        u_log = torch.zeros(M, N, m, dtype=e.dtype, device=e.device)
+        e.kern.sls_closed_loop(dev(self.A), dev(self.B), dev(np.asarray(K)), dev(np.asarray(k)), dev(x0), x_log, u_log,
+                               stream=torch.cuda.current_stream().cuda_stream)
+        return x_log.cpu().numpy().astype(np.float64), u_log.cpu().numpy().astype(np.float64)
+
+    # ---- out of scope (dense batch-form LQT) ------------------------------------------------------------------------
+    def _dense_batch_form(self, *a, **k):
+        raise NotImplementedError("dense batch-form LQT solvers (solve_batch, ADMM_LQT_Batch, replanning) are not built; "
+                                  "the DP-form methods solve the same problems")
+
+    solve_batch = ADMM_LQT_Batch = _dense_batch_form
+    initialize_replanning_procedure = replan_feedforward = get_trajectory_batch = _dense_batch_form

@@ -293,6 +293,46 @@ int isls_admm_update_f64(const isls_admm_args *a, void *stream);
 int isls_admm_update_f32(const isls_admm_args *a, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * SLS-ADMM with chance constraints on the controls (config 5 of BASELINE.json).
+ * Replaces the iteration of SLS.ADMM_SLS (isls/sls.py:319-454, project_u only) with project_u given as
+ * set descriptors: project_set_convex (isls/projections.py:289-374) over the R = N*m rows
+ * y = [d_u, phi_u] (dimension D = 1 + p) of one problem per call of the reference:
+ *   x_u = Linv (r_side + rr .* (z - lmb)) ;  z = Proj(alpha x_u + (1-alpha) z + lmb) ;  lmb += x_u - z
+ *   prim = |rr .* (x_u - z)|_F , dual = |rr .* (z - z_prev)|_F
+ *   stop if both < tol, else if both relative changes (+1e-30) < rel_tol = 1e-2      (sls.py:417-430)
+ * (once the primal residual has reached rounding level its relative change is noise, so the iteration at which
+ * the second rule fires is not reproducible to the last step, in the reference either; rel_tol = 0 disables it)
+ * z and lmb start at zero.  Linv [R,R] = (Su'Q Su + R + Rr)^-1 (symmetric) is shared by the P problems
+ * (same dynamics and weights), r_side [P,R,D] = [Su'Q xd_p , -Su'Q Sx] and the constraint sets may differ
+ * per problem.  rr [R] is the diagonal of Rr.  logs [P,max_iter,2] receives (prim, dual) per executed
+ * iteration (rows beyond iters[p] are left untouched).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_sls_admm_args {
+    int32_t P, R, D, max_iter;
+    double alpha, tol;
+    double rel_tol;           /* relative-change stop rule; the reference hard-codes 1e-2 (sls.py:426)   */
+    const void *Linv;
+    const void *r_side;
+    const void *rr;
+    isls_project_args proj;   /* nsets, sets, rho, max_iter, threshold are used (d = D)          */
+    void *x_u;                /* [P,R,D] out: du = x_u[:,:,0], phi_u[:, :p] = x_u[:,:,1:]         */
+    void *z, *lmb;            /* [P,R,D] out, nullable                                            */
+    void *logs;               /* nullable                                                         */
+    int32_t *iters;           /* [P] nullable                                                     */
+} isls_sls_admm_args;
+
+int isls_sls_admm_f64(const isls_sls_admm_args *a, void *stream);
+int isls_sls_admm_f32(const isls_sls_admm_args *a, void *stream);
+
+/* Closed loop of the dense causal SLS controller for M initial states (Monte-Carlo evaluation of the notebooks):
+ *   u_i = k_i + sum_{j<=i} K[i, j] x_j ,  x_{i+1} = A x_i + B u_i          (isls/sls_base.py:91-105, noise_scale = 0)
+ * A [n,n], B [n,m], K [N m, N n], k [N m], x0 [M,n] -> x_log [M,N,n], u_log [M,N,m]. */
+int isls_sls_closed_loop_f64(int32_t M, int32_t N, int32_t n, int32_t m, const void *A, const void *B, const void *K,
+                             const void *k, const void *x0, void *x_log, void *u_log, void *stream);
+int isls_sls_closed_loop_f32(int32_t M, int32_t N, int32_t n, int32_t m, const void *A, const void *B, const void *K,
+                             const void *k, const void *x0, void *x_log, void *u_log, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Quadratic via-point cost expansion about the nominal (the `Cts is None` branch of
  * backward_pass_DP, isls/isls.py:263-271, written out as arrays, plus the ADMM regulariser):
  *   Cxx[b,t] = 2 Q_t (+ 2 Qr_t) ; Cuu[b,t] = 2 u_std I (+ 2 Rr_t)

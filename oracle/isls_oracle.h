@@ -16,6 +16,10 @@ extern "C" {
     int oracle_reduce_convergence_##sfx(int32_t B, const void *cost, const void *res,                 \
                                         const int32_t *active, const int32_t *status, void *out5);    \
     int oracle_project_rows_##sfx(const isls_project_args *a);                                        \
+    int oracle_sls_admm_##sfx(const isls_sls_admm_args *a);                                           \
+    int oracle_sls_closed_loop_##sfx(int32_t M, int32_t N, int32_t n, int32_t m, const void *A,       \
+                                     const void *B, const void *K, const void *k, const void *x0,     \
+                                     void *x_log, void *u_log);                                       \
     int oracle_ilqr_admm_outer_##sfx(const isls_outer_args *a);
 ORACLE_DECL(f64)
 ORACLE_DECL(f32)

@@ -813,6 +813,102 @@ int FN(oracle_project_rows)(const isls_project_args *a)
     return rc;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * SLS-ADMM, control chance constraints: the loop of SLS.ADMM_SLS, isls/sls.py:363-449 (project_u only;
+ * f_argmin 375-384, z/lambda update 398-403, Rr-scaled Frobenius residuals 405-412, stop rules 415-430).
+ * ------------------------------------------------------------------------------------------- */
+int FN(oracle_sls_admm)(const isls_sls_admm_args *a)
+{
+    const int P = a->P, R = a->R, D = a->D;
+    if (P < 0 || R < 1 || D < 1 || D > ISLS_MAX_ROW_DIM || a->max_iter < 1 || !a->Linv || !a->r_side || !a->rr || !a->x_u) return ISLS_ERR_ARG;
+    const REAL *Linv = (const REAL *)a->Linv, *rr = (const REAL *)a->rr;
+    const REAL alpha = (REAL)a->alpha, tol = (REAL)a->tol;
+    int rc_all = ISLS_OK;
+#pragma omp parallel for schedule(dynamic)
+    for (int p = 0; p < P; ++p) {
+        const REAL *rside = (const REAL *)a->r_side + (int64_t)p * R * D;
+        REAL *buf = (REAL *)calloc((size_t)R * D * 6, sizeof(REAL));
+        REAL *x = buf, *z = x + R * D, *lm = z + R * D, *rhs = lm + R * D, *v = rhs + R * D, *zn = v + R * D;
+        isls_project_args pr = a->proj;
+        pr.P = 1; pr.R = R; pr.d = D; pr.y_in = v; pr.y_out = zn; pr.in_sp = pr.out_sp = 0; pr.in_sr = pr.out_sr = D;
+        pr.iters = 0; pr.active = 0;
+        for (int s = 0; s < pr.nsets; ++s) {               /* this problem's operands */
+            if (pr.sets[s].A) pr.sets[s].A = (const REAL *)pr.sets[s].A + (int64_t)p * pr.sets[s].A_sp;
+            if (pr.sets[s].b) pr.sets[s].b = (const REAL *)pr.sets[s].b + (int64_t)p * pr.sets[s].b_sp;
+            if (pr.sets[s].par) pr.sets[s].par = (const REAL *)pr.sets[s].par + (int64_t)p * pr.sets[s].par_sp;
+            pr.sets[s].A_sp = pr.sets[s].b_sp = pr.sets[s].par_sp = 0;
+        }
+        REAL prim = (REAL)1e6, dual = (REAL)1e6;
+        int it = 0;
+        for (int j = 0; j < a->max_iter; ++j) {
+            ++it;
+            for (int i = 0; i < R; ++i)
+                for (int c = 0; c < D; ++c) rhs[i * D + c] = rside[i * D + c] + rr[i] * (z[i * D + c] - lm[i * D + c]);
+            for (int i = 0; i < R; ++i)
+                for (int c = 0; c < D; ++c) {
+                    REAL acc = 0;
+                    for (int k = 0; k < R; ++k) acc += Linv[(int64_t)i * R + k] * rhs[k * D + c];
+                    x[i * D + c] = acc;
+                }
+            for (int e = 0; e < R * D; ++e) v[e] = (alpha * x[e] + (1 - alpha) * z[e]) + lm[e];
+            int rc = FN(oracle_project_rows)(&pr);
+            if (rc != ISLS_OK) { rc_all = rc; break; }
+            REAL prev_p = prim, prev_d = dual, p2 = 0, d2 = 0;
+            for (int i = 0; i < R; ++i)
+                for (int c = 0; c < D; ++c) {
+                    const int e = i * D + c;
+                    REAL prs = x[e] - zn[e], dz = zn[e] - z[e];
+                    lm[e] += prs;
+                    z[e] = zn[e];
+                    p2 += (rr[i] * prs) * (rr[i] * prs);
+                    d2 += (rr[i] * dz) * (rr[i] * dz);
+                }
+            prim = SQRT(p2); dual = SQRT(d2);
+            if (a->logs) { REAL *lg = (REAL *)a->logs + ((int64_t)p * a->max_iter + j) * 2; lg[0] = prim; lg[1] = dual; }
+            if (prim < tol && dual < tol) break;
+            REAL pc = FABS(prev_p - prim) / (prev_p + (REAL)1e-30), dc = FABS(prev_d - dual) / (prev_d + (REAL)1e-30);
+            if (pc < (REAL)a->rel_tol && dc < (REAL)a->rel_tol) break;
+        }
+        for (int e = 0; e < R * D; ++e) {
+            ((REAL *)a->x_u)[(int64_t)p * R * D + e] = x[e];
+            if (a->z) ((REAL *)a->z)[(int64_t)p * R * D + e] = z[e];
+            if (a->lmb) ((REAL *)a->lmb)[(int64_t)p * R * D + e] = lm[e];
+        }
+        if (a->iters) a->iters[p] = it;
+        free(buf);
+    }
+    return rc_all;
+}
+
+/* Closed loop of the dense causal controller, isls/sls_base.py:91-105 (noise_scale = 0). */
+int FN(oracle_sls_closed_loop)(int32_t M, int32_t N, int32_t n, int32_t m, const void *A_, const void *B_, const void *K_,
+                               const void *k_, const void *x0_, void *x_log, void *u_log)
+{
+    const REAL *A = (const REAL *)A_, *B = (const REAL *)B_, *K = (const REAL *)K_, *k = (const REAL *)k_, *x0 = (const REAL *)x0_;
+    if (M < 0 || N < 1 || n < 1 || m < 1 || !A || !B || !K || !k || !x0 || !x_log || !u_log) return ISLS_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int s = 0; s < M; ++s) {
+        REAL *xs = (REAL *)x_log + (int64_t)s * N * n, *us = (REAL *)u_log + (int64_t)s * N * m;
+        for (int j = 0; j < n; ++j) xs[j] = x0[(int64_t)s * n + j];
+        for (int i = 0; i < N; ++i) {
+            for (int r = 0; r < m; ++r) {
+                const REAL *Kr = K + (int64_t)(i * m + r) * N * n;
+                REAL acc = 0;
+                for (int j = 0; j < (i + 1) * n; ++j) acc += xs[j] * Kr[j];
+                us[i * m + r] = acc + k[i * m + r];
+            }
+            if (i + 1 < N)
+                for (int a = 0; a < n; ++a) {
+                    REAL acc = 0;
+                    for (int j = 0; j < n; ++j) acc += A[a * n + j] * xs[i * n + j];
+                    for (int r = 0; r < m; ++r) acc += B[a * m + r] * us[i * m + r];
+                    xs[(i + 1) * n + a] = acc;
+                }
+        }
+    }
+    return ISLS_OK;
+}
+
 /* One outer iteration: gain -> J x [ff -> rollout -> update]  (SURVEY 3.3 / 8d metric definition). */
 int FN(oracle_ilqr_admm_outer)(const isls_outer_args *a)
 {

@@ -593,7 +593,75 @@ def gen_projections():
     save("g6_projections.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G7: config 5 -- SLS.ADMM_SLS with SOC chance constraints on the controls (unmodified SLS)
+# ---------------------------------------------------------------------------------------------
+def gen_sls():
+    """`notebooks/Double integrator/LQR and SLS with control bounds.ipynb` cells 3-16 at N=50 (SURVEY config 5), for the
+    1-D and the 3-D double integrator and a handful of problems that differ in target, control bound and x0 variance.
+    Every problem is solved by its own unmodified reference `SLS` object."""
+    import contextlib
+    import io
+    from scipy.stats import norm
+    from isls import SLS as RefSLS
+    from isls.utils import get_double_integrator_AB as ref_di
+    rng = np.random.default_rng(11)
+    for tag, nb_dim, nprob in (("d1", 1, 4), ("d3", 3, 2)):
+        N, dt = 50, 1.0 / 50
+        n, m, p = 2 * nb_dim, nb_dim, nb_dim
+        A, B = ref_di(nb_dim, nb_deriv=2, dt=dt)
+        u_std = 1e-2
+        out = dict(A=A, B=B, N=np.array(N), u_std=np.array(u_std), rho_u=np.array(1e2), alpha=np.array(1.0), tol=np.array(1e-3),
+                   max_iter=np.array(50), inner_rho=np.array(10.0), inner_max_iter=np.array(100), inner_threshold=np.array(1e-3))
+        targets, bounds, variances, conf = [], [], [], []
+        res = dict(du=[], phi_u=[], logs=[], n_it=[], xd=[], A0=[], A1=[], b0=[], b1=[], du0=[], PHI_U=[], K=[], k=[],
+                   mc_x0=[], mc_x=[], mc_u=[])
+        for b in range(nprob):
+            target = np.concatenate([rng.uniform(0.5, 1.5, nb_dim), np.zeros(nb_dim)]) if b else np.concatenate([np.ones(nb_dim), np.zeros(nb_dim)])
+            upper_u = [5.0, 4.0, 6.0, 5.5][b % 4]
+            var_x0 = [0.01, 0.005, 0.02, 0.01][b % 4]
+            psi_inv = norm.ppf([0.95, 0.9, 0.95, 0.82][b % 4])
+            sls = RefSLS(n, m, N)
+            sls.AB = [A, B]
+            zs = np.stack([np.zeros(n), target])
+            Qs = np.stack([np.zeros((n, n)), 1e6 * np.eye(n)])
+            seq = np.zeros(N, dtype=np.int32)
+            seq[N - 1] = 1
+            sls.set_quadratic_cost(zs, Qs, seq, u_std)
+            # cell 15: SOC rows  psi^-1 ||Sigma^1/2 y|| <= u_max - mu'y  and the mirrored lower bound
+            mu = np.zeros(p + 1)
+            mu[0] = 1.0
+            sigma = np.zeros(p + 1)
+            sigma[1:] = var_x0
+            Au = np.diag(np.sqrt(sigma))
+            A_ = [np.concatenate([Au, (-mu / psi_inv)[None]], 0), np.concatenate([Au, (mu / psi_inv)[None]], 0)]
+            b_ = [np.append(np.zeros(p + 1), upper_u / psi_inv), np.append(np.zeros(p + 1), upper_u / psi_inv)]
+            project_u = lambda y: refproj.project_set_convex(y, A_, b_, projections=[refproj.project_soc_unit] * 2,   # noqa: E731
+                                                             rho=1e1, max_iter=100, threshold=1e-3)
+            with contextlib.redirect_stdout(io.StringIO()):
+                PHI_U0, du0 = sls.solve_sls()
+                sls.l_side_invs = None
+                du, phi_u, logs = sls.ADMM_SLS(project_u=project_u, max_iter=50, rho_u=1e2, alpha=1.0, tol=1e-3, verbose=0, log=True)
+                K, k = sls.controller(phi_u, du)
+            lg = np.full((50, 2), np.nan)
+            lg[:len(logs)] = np.stack(logs)
+            x0s = np.zeros((16, n))
+            x0s[:, :p] = rng.normal(scale=np.sqrt(var_x0), size=(16, p))
+            xm, um = sls.get_trajectory_sls(x0s, K, k, noise_scale=0.0)
+            res["du"].append(du), res["phi_u"].append(phi_u), res["logs"].append(lg), res["n_it"].append(len(logs))
+            res["xd"].append(np.asarray(sls.xd).reshape(-1)), res["A0"].append(A_[0]), res["A1"].append(A_[1])
+            res["b0"].append(b_[0]), res["b1"].append(b_[1]), res["du0"].append(du0), res["PHI_U"].append(PHI_U0)
+            res["K"].append(K), res["k"].append(k), res["mc_x0"].append(x0s), res["mc_x"].append(xm), res["mc_u"].append(um)
+            targets.append(target), bounds.append(upper_u), variances.append(var_x0), conf.append(psi_inv)
+            print(tag, "problem", b, "ADMM_SLS iterations", len(logs), "max |du|", np.max(np.abs(du)))
+        out.update({k_: np.stack(v) for k_, v in res.items()})
+        out.update(targets=np.stack(targets), upper_u=np.array(bounds), var_x0=np.array(variances), psi_inv=np.array(conf))
+        if tag == "d1":   # pin: the notebook's own run (N=100 there; here the N=50 variant of SURVEY config 5)
+            out["Sw"], out["Su"] = sls.Sw, sls.Su
+        save(f"g7_sls_{tag}.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj"]
+    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls"]
     for w in which:
-        {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections}[w]()
+        {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections, "sls": gen_sls}[w]()

@@ -35,14 +35,14 @@ def test_struct_layouts_match_header():
     """sizeof of every argument struct as compiled from the header by gcc == ctypes' layout."""
     import subprocess
     import tempfile
-    names = ["gain", "ff", "ff_prepare", "rollout", "admm", "project", "expand", "linearize", "accept", "outer"]
+    names = ["gain", "ff", "ff_prepare", "rollout", "admm", "project", "sls_admm", "expand", "linearize", "accept", "outer"]
     src = '#include <stdio.h>\n#include "isls_hip.h"\nint main(){' + "".join(
         f'printf("%zu\\n", sizeof(isls_{n}_args));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "s"), os.path.join(d, "s.c")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
-    structs = [capi.GainArgs, capi.FfArgs, capi.FfPrepareArgs, capi.RolloutArgs, capi.AdmmArgs, capi.ProjectArgs, capi.ExpandArgs, capi.LinearizeArgs,
+    structs = [capi.GainArgs, capi.FfArgs, capi.FfPrepareArgs, capi.RolloutArgs, capi.AdmmArgs, capi.ProjectArgs, capi.SlsAdmmArgs, capi.ExpandArgs, capi.LinearizeArgs,
                capi.AcceptArgs, capi.OuterArgs]
     assert sizes == [ctypes.sizeof(s) for s in structs]
 

@@ -265,3 +265,34 @@ def test_projection_kernels(oracle, golden):
     # fp32
     o, io, h, ih = _dual_project(oracle, x.astype(np.float32), _car_keepout_sets(np.float32), rho=10.0, max_iter=15, threshold=1e-3)
     assert np.max(np.abs(o - h)) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["d1", "d3"])
+def test_config5_sls_admm_kernels(oracle, golden, tag):
+    """isls_sls_admm / isls_sls_closed_loop on the device against the oracle (fp64: every iteration, every problem) and
+    against the reference's golden outputs (fp64 and fp32: the metric's 1e-4)."""
+    import torch
+    from dual import hip_kernels
+    from test_oracle_golden import _check_sls_admm, _run_sls_admm, _sls_case
+    g = golden(f"g7_sls_{tag}.npz")
+    c = _sls_case(g)
+    hip = hip_kernels()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()     # noqa: E731
+    host = lambda t: tuple(x.cpu().numpy() for x in t)                      # noqa: E731
+    # same iteration counts and logs as the oracle with the reference's stop rules (same arithmetic, fp64)
+    xo, lo, io = _run_sls_admm(oracle, c, g, rel_tol=0.0)
+    xh, lh, ih = host(_run_sls_admm(hip, c, g, wrap=dev, rel_tol=0.0))
+    assert np.array_equal(io, ih)
+    for b in range(c["P"]):
+        assert np.max(np.abs(xo[b] - xh[b])) / np.max(np.abs(xo[b])) < 1e-9
+        assert np.nanmax(np.abs(lo[b] - lh[b]) / np.maximum(1e-6, np.abs(lo[b]))) < 1e-6
+    # against the reference itself
+    _check_sls_admm(lambda sel, mi, rt: host(_run_sls_admm(hip, c, g, wrap=dev, sel=sel, max_iter=mi, rel_tol=rt)), c, g, 1e-7)
+    _check_sls_admm(lambda sel, mi, rt: host(_run_sls_admm(hip, c, g, dtype=np.float32, wrap=dev, sel=sel, max_iter=mi, rel_tol=rt)),
+                    c, g, 2e-3, only_converged=True)
+    # closed-loop Monte-Carlo rollout with the reference's controller
+    M = g["mc_x0"].shape[1]
+    xl, ul = dev(np.zeros((M, c["N"], c["n"]))), dev(np.zeros((M, c["N"], c["m"])))
+    hip.sls_closed_loop(dev(g["A"]), dev(g["B"]), dev(g["K"][0]), dev(g["k"][0]), dev(g["mc_x0"][0]), xl, ul)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(xl.cpu().numpy() - g["mc_x"][0])) < 1e-9 and np.max(np.abs(ul.cpu().numpy() - g["mc_u"][0])) < 1e-8
