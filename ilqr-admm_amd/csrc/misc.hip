@@ -20,6 +20,8 @@ struct ExpP {
     const T *xhat, *uhat;
     T *Cxx, *Cuu, *c0x, *c0u, *cost;
     const int32_t *active;
+    int cost_model;
+    const T *cpar;
 };
 
 template <typename T>
@@ -31,6 +33,45 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpP<T> p)
     const T *Qtab = p.Qtab + (int64_t)b * p.Qtab_sb, *ztab = p.ztab + (int64_t)b * p.ztab_sb;
     const int64_t bN = (int64_t)b * N;
     T cx_sum = T(0), cu_sum = T(0);
+    if (p.cost_model == ISLS_COST_PHUBER) {
+        // gradient and (diagonal) Hessian of sum_t [cu.u^2 + cx.ph(x,px)] + cf.ph(x_{N-1},pf), ph = sqrt(x^2+p^2)-p:
+        // what Tutorial.ipynb cell 16 obtains from autograd (ph' = x/s, ph'' = p^2/s^3 with s = sqrt(x^2+p^2))
+        const T *cu = p.cpar, *cx = cu + m, *px = cx + n, *cf = px + n, *pf = cf + n;
+        for (int e = lane; e < N * n; e += kWave) {
+            const int t = e / n, i = e - t * n;
+            const T x = p.xhat ? p.xhat[bN * n + e] : T(0);
+            const T s1 = sqrt(x * x + px[i] * px[i]);
+            T g = cx[i] * (x / s1), h = cx[i] * ((px[i] * px[i]) / (s1 * s1 * s1)), c = cx[i] * (s1 - px[i]);
+            if (t == N - 1) {
+                const T s2 = sqrt(x * x + pf[i] * pf[i]);
+                g += cf[i] * (x / s2);
+                h += cf[i] * ((pf[i] * pf[i]) / (s2 * s2 * s2));
+                c += cf[i] * (s2 - pf[i]);
+            }
+            p.c0x[bN * n + e] = g;
+            cx_sum += c;
+            if (p.Cxx) {
+                T *row = p.Cxx + (bN + t) * n * n + i * n;
+                for (int j = 0; j < n; ++j) row[j] = (j == i ? h : T(0)) + (p.Qr.p ? T(2) * p.Qr.at(b, t)[i * n + j] : T(0));
+            }
+        }
+        for (int e = lane; e < N * m; e += kWave) {
+            const int t = e / m, i = e - t * m;
+            const T uu = p.uhat ? p.uhat[bN * m + e] : T(0);
+            p.c0u[bN * m + e] = T(2) * (cu[i] * uu);
+            cu_sum += cu[i] * (uu * uu);
+            if (p.Cuu) {
+                T *row = p.Cuu + (bN + t) * m * m + i * m;
+                for (int j = 0; j < m; ++j) row[j] = (j == i ? T(2) * cu[i] : T(0)) + (p.Rr.p ? T(2) * p.Rr.at(b, t)[i * m + j] : T(0));
+            }
+        }
+        if (p.cost) {
+            cx_sum = wave_sum(cx_sum);
+            cu_sum = wave_sum(cu_sum);
+            if (lane == 0) p.cost[b] = cx_sum + cu_sum;
+        }
+        return;
+    }
     // c0x[t,i] = 2 * sum_j Q_t[i,j] (xhat[t,j] - z_t[j]);   cost_x = sum d_i (Q d)_i
     for (int e = lane; e < N * n; e += kWave) {
         const int t = e / n, i = e - t * n;
@@ -72,7 +113,9 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpP<T> p)
 template <typename T>
 int launch_expand(const isls_expand_args &a, hipStream_t s)
 {
-    if (a.B < 0 || a.N < 1 || a.n < 1 || a.m < 1 || !a.Qtab || !a.ztab || !a.seq || !a.c0x || !a.c0u) return ISLS_ERR_ARG;
+    if (a.B < 0 || a.N < 1 || a.n < 1 || a.m < 1 || !a.c0x || !a.c0u) return ISLS_ERR_ARG;
+    if (a.cost_model == ISLS_COST_VIA && (!a.Qtab || !a.ztab || !a.seq)) return ISLS_ERR_ARG;
+    if (a.cost_model != ISLS_COST_VIA && (a.cost_model != ISLS_COST_PHUBER || !a.cost_par)) return ISLS_ERR_UNSUPPORTED;
     if (a.B == 0) return ISLS_OK;
     ExpP<T> p;
     p.B = a.B; p.N = a.N; p.n = a.n; p.m = a.m;
@@ -82,6 +125,7 @@ int launch_expand(const isls_expand_args &a, hipStream_t s)
     p.xhat = (const T *)a.xhat; p.uhat = (const T *)a.uhat;
     p.Cxx = (T *)a.Cxx; p.Cuu = (T *)a.Cuu; p.c0x = (T *)a.c0x; p.c0u = (T *)a.c0u; p.cost = (T *)a.cost;
     p.active = a.active;
+    p.cost_model = a.cost_model; p.cpar = (const T *)a.cost_par;
     hipLaunchKernelGGL((expand_kernel<T>), dim3(a.B), dim3(64), 0, s, p);
     return check_launch();
 }
@@ -164,6 +208,48 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinP<T> p)
         }
         return;
     }
+    if (p.model == ISLS_MODEL_TASSA) {
+        // Tutorial.ipynb cell 8 differentiated by hand (the notebook uses autograd):
+        //   f = dt v, sw = sin w, cw = cos w, r = sqrt(d^2 - (sw f)^2), b = f cw + d - r
+        //   db/df = cw + sw^2 f / r, db/dw = -f sw + sw cw f^2 / r, d(asin(sw f / d))/dw = cw f / r, /df = sw / r
+        // tab[t] = {b, db/df, db/dw, sin th, cos th, cw f / r, sw / r}
+        const T d = par[1];
+        for (int t = lane; t < N; t += kWave) {
+            const T *x = p.xhat + (bN + t) * 4, *u = p.uhat + (bN + t) * 2;
+            const T f = dt * x[3], sw = sin(u[0]), cw = cos(u[0]);
+            const T r = sqrt(d * d - (sw * f) * (sw * f));
+            tab[t * 8 + 0] = (f * cw + d) - r;
+            tab[t * 8 + 1] = cw + (sw * sw * f) / r;
+            tab[t * 8 + 2] = -f * sw + (sw * cw * f * f) / r;
+            tab[t * 8 + 3] = sin(x[2]);
+            tab[t * 8 + 4] = cos(x[2]);
+            tab[t * 8 + 5] = (cw * f) / r;
+            tab[t * 8 + 6] = sw / r;
+        }
+        __syncthreads();
+        for (int e = lane; e < N * 16; e += kWave) {
+            const int t = e / 16, r = (e % 16) / 4, c = e % 4;
+            const T *tb = tab + t * 8;
+            T v = (r == c) ? T(1) : T(0);
+            if (r == 0 && c == 2) v = -tb[0] * tb[3];
+            else if (r == 1 && c == 2) v = tb[0] * tb[4];
+            else if (r == 0 && c == 3) v = (tb[1] * dt) * tb[4];
+            else if (r == 1 && c == 3) v = (tb[1] * dt) * tb[3];
+            else if (r == 2 && c == 3) v = tb[6] * dt;
+            A[e] = v;
+        }
+        for (int e = lane; e < N * 8; e += kWave) {
+            const int t = e / 8, r = (e % 8) / 2, c = e % 2;
+            const T *tb = tab + t * 8;
+            T v = T(0);
+            if (r == 0 && c == 0) v = tb[2] * tb[4];
+            else if (r == 1 && c == 0) v = tb[2] * tb[3];
+            else if (r == 2 && c == 0) v = tb[5];
+            else if (r == 3 && c == 1) v = dt;
+            Bm[e] = v;
+        }
+        return;
+    }
     // car-simple (Car notebooks cell 6): tab[t] = {sin th, cos th, v, u0}
     for (int t = lane; t < N; t += kWave) {
         const T *x = p.xhat + (bN + t) * 4, *u = p.uhat + (bN + t) * 2;
@@ -198,7 +284,8 @@ int launch_linearize(const isls_linearize_args &a, hipStream_t s)
     if (a.model == ISLS_MODEL_ARM3R && !(a.n == 9 && a.m == 3)) return ISLS_ERR_UNSUPPORTED;
     if (a.model == ISLS_MODEL_CAR && !(a.n == 4 && a.m == 2)) return ISLS_ERR_UNSUPPORTED;
     if (a.model == ISLS_MODEL_DI && !(a.n == 2 * a.m)) return ISLS_ERR_UNSUPPORTED;
-    if (a.model < ISLS_MODEL_LTI || a.model > ISLS_MODEL_DI) return ISLS_ERR_UNSUPPORTED;
+    if (a.model == ISLS_MODEL_TASSA && !(a.n == 4 && a.m == 2)) return ISLS_ERR_UNSUPPORTED;
+    if (a.model < ISLS_MODEL_LTI || a.model > ISLS_MODEL_TASSA) return ISLS_ERR_UNSUPPORTED;
     if ((size_t)a.N * 8 * sizeof(T) > 60000) return ISLS_ERR_UNSUPPORTED;
     if (a.B == 0) return ISLS_OK;
     LinP<T> p;

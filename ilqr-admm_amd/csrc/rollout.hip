@@ -37,6 +37,8 @@ struct RoP {
     T *cost_all, *cost_new, *x_out, *u_out;
     int32_t *best, *status;
     const int32_t *active;
+    int cost_model;
+    const T *cpar;                 // ISLS_COST_PHUBER parameters [NU + 4 NX]
 };
 
 // ---- built-in forward models -------------------------------------------------
@@ -122,6 +124,23 @@ struct Model<T, 4, 2, ISLS_MODEL_CAR> {        // car-simple [x, y, theta, v]  (
     }
 };
 
+template <typename T>
+struct Model<T, 4, 2, ISLS_MODEL_TASSA> {      // Tassa car-parking [x, y, theta, v], u = [w, a]  (Tutorial.ipynb cell 8)
+    static constexpr int LDS_WORDS = 0;
+    T dt, d;
+    __device__ __forceinline__ void load(const T *par, T *, int, int) { dt = par[0]; d = par[1]; }
+    __device__ __forceinline__ void step(const T (&x)[4], const T (&u)[2], T (&xn)[4]) const
+    {
+        const T f = dt * x[3];
+        const T sw = sin(u[0]) * f;
+        const T b = (f * cos(u[0]) + d) - sqrt(d * d - sw * sw);
+        xn[0] = x[0] + b * cos(x[2]);
+        xn[1] = x[1] + b * sin(x[2]);
+        xn[2] = x[2] + asin(sw / d);
+        xn[3] = x[3] + u[1] * dt;
+    }
+};
+
 constexpr int kRolloutDepth = 3;   // steps of record elements in flight per lane
 constexpr int kMaxSeg = 10;        // winner replay: at most this many segments
 
@@ -196,6 +215,19 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
     slot_sync();
     const T *Qtab = p.Qtab + (int64_t)bb * p.Qtab_sb, *ztab = p.ztab + (int64_t)bb * p.ztab_sb;
     const T ustd = p.u_std;
+    // pseudo-Huber cost model: compiled into the kernels of the Tassa model only, selected at run time
+    constexpr bool kHasPH = MODEL == ISLS_MODEL_TASSA;
+    const bool phuber = kHasPH && p.cost_model == ISLS_COST_PHUBER;
+    T ph_cu[NU], ph_cx[NX], ph_px[NX], ph_cf[NX], ph_pf[NX];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) ph_cu[r] = phuber ? p.cpar[r] : T(0);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        ph_cx[j] = phuber ? p.cpar[NU + j] : T(0);
+        ph_px[j] = phuber ? p.cpar[NU + NX + j] : T(1);
+        ph_cf[j] = phuber ? p.cpar[NU + 2 * NX + j] : T(0);
+        ph_pf[j] = phuber ? p.cpar[NU + 3 * NX + j] : T(1);
+    }
     const T *x0p = p.x0 ? p.x0 + (int64_t)bb * NX : (p.xhat ? p.xhat + bN * NX : nullptr);
 
 #ifdef ISLS_DIAG
@@ -282,6 +314,17 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
                     const unsigned long long mm = w == 0 ? qm0 : (w == 1 ? qm1 : (w == 2 ? qm2 : qm3));
                     nz = live && ((mm >> (t & 63)) & 1ull) != 0;
                 }
+                if (kHasPH && phuber) {                        // sum_i cu_i u_i^2 + cx_i ph(x_i,px_i) (+ final term)
+                    nz = false;
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) cst1 += ph_cx[j] * (sqrt(x[j] * x[j] + ph_px[j] * ph_px[j]) - ph_px[j]);
+                    if (t == N - 1) {
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) cst1 += ph_cf[j] * (sqrt(x[j] * x[j] + ph_pf[j] * ph_pf[j]) - ph_pf[j]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < NU; ++r) cu1 += ph_cu[r] * (u[r] * u[r]);
+                }
                 if (nz) {
                     const int sq = seqp[t];
                     const T *Q = Qtab + (int64_t)sq * NX * NX, *z = ztab + (int64_t)sq * NX;
@@ -296,8 +339,10 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
                         cst1 += dq[i] * acc;
                     }
                 }
+                if (!(kHasPH && phuber)) {
 #pragma unroll
-                for (int r = 0; r < NU; ++r) cu1 += u[r] * (ustd * u[r]);
+                    for (int r = 0; r < NU; ++r) cu1 += u[r] * (ustd * u[r]);
+                }
                 if (has_wq) {
 #pragma unroll
                     for (int j = 0; j < NX; ++j) { const T df = x[j] - rec[O_RX + j]; ag1 += (df * df) * rec[O_WQ + j]; }
@@ -407,7 +452,8 @@ template <typename T>
 int launch_rollout(const isls_rollout_args &a, hipStream_t s)
 {
     if (a.B < 0 || a.N < 1 || a.L < 1 || a.L > 64) return ISLS_ERR_ARG;
-    if (!a.model_par || !a.K || !a.k || !a.alphas || !a.Qtab || !a.ztab || !a.seq || !a.x_out || !a.u_out) return ISLS_ERR_ARG;
+    if (!a.model_par || !a.K || !a.k || !a.alphas || !a.x_out || !a.u_out) return ISLS_ERR_ARG;
+    if (a.cost_model == ISLS_COST_VIA && (!a.Qtab || !a.ztab || !a.seq)) return ISLS_ERR_ARG;
     if (!(a.flags & ISLS_RO_ABSOLUTE) && (!a.xhat || !a.uhat)) return ISLS_ERR_ARG;
     if ((a.flags & ISLS_RO_ABSOLUTE) && !a.x0) return ISLS_ERR_ARG;
     if ((a.flags & ISLS_RO_ACCEPT_TEST) && !a.cost_cur) return ISLS_ERR_ARG;
@@ -427,6 +473,9 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s)
     p.cost_cur = (const T *)a.cost_cur;
     p.cost_all = (T *)a.cost_all; p.cost_new = (T *)a.cost_new; p.x_out = (T *)a.x_out; p.u_out = (T *)a.u_out;
     p.best = a.best; p.status = a.status; p.active = a.active;
+    p.cost_model = a.cost_model; p.cpar = (const T *)a.cost_par;
+    if (a.cost_model != ISLS_COST_VIA && (a.cost_model != ISLS_COST_PHUBER || a.model != ISLS_MODEL_TASSA || !a.cost_par))
+        return ISLS_ERR_UNSUPPORTED;
     const int GL = a.L > 8 ? a.L : 8, TPW = kWave / GL;
     const int grid = (a.B + TPW - 1) / TPW;
     // winner replay geometry: NSEG segments of S steps, NSEG <= lanes of a slot
@@ -459,6 +508,7 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s)
     else if (a.n == 6 && a.m == 3 && a.model == ISLS_MODEL_DI) LAUNCH(6, 3, ISLS_MODEL_DI)
     else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_DI) LAUNCH(4, 2, ISLS_MODEL_DI)
     else if (a.n == 2 && a.m == 1 && a.model == ISLS_MODEL_DI) LAUNCH(2, 1, ISLS_MODEL_DI)
+    else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_TASSA) LAUNCH(4, 2, ISLS_MODEL_TASSA)
     else return ISLS_ERR_UNSUPPORTED;
 #undef LAUNCH
 #undef LAUNCH_G

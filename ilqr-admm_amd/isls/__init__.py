@@ -6,7 +6,7 @@ imports the same names.  The numerics run in hand-written HIP kernels (csrc/) th
 include/isls_hip.h; there is no CPU fallback: constructing a solver without the built library or without a
 HIP device raises.
 """
-from . import _capi, models  # noqa: F401
+from . import _capi, costs, models  # noqa: F401
 from .admm import ADMM  # noqa: F401
 from .utils import get_double_integrator_AB, find_mus, find_precs  # noqa: F401
 from .projections import *  # noqa: F401,F403

@@ -20,7 +20,8 @@ except Exception:  # pragma: no cover
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
-MODEL_LTI, MODEL_ARM3R, MODEL_CAR, MODEL_DI = 0, 1, 2, 3
+MODEL_LTI, MODEL_ARM3R, MODEL_CAR, MODEL_DI, MODEL_TASSA = 0, 1, 2, 3, 4
+COST_VIA, COST_PHUBER = 0, 1
 RO_NAN_TO_1E5, RO_ACCEPT_TEST, RO_ABSOLUTE = 1, 2, 4
 PROJ_NONE, PROJ_BOX, PROJ_SETS = 0, 1, 2
 
@@ -75,7 +76,8 @@ class RolloutArgs(C.Structure):
                 ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
                 ("cost_cur", C.c_void_p), ("cost_all", C.c_void_p), ("best", C.c_void_p),
                 ("cost_new", C.c_void_p), ("x_out", C.c_void_p), ("u_out", C.c_void_p),
-                ("status", C.c_void_p), ("active", C.c_void_p)]
+                ("status", C.c_void_p), ("active", C.c_void_p),
+                ("cost_model", C.c_int32), ("_pad2", C.c_int32), ("cost_par", C.c_void_p)]
 
 
 class AdmmArgs(C.Structure):
@@ -98,7 +100,8 @@ class ExpandArgs(C.Structure):
                 ("Qr", View), ("Rr", View),
                 ("xhat", C.c_void_p), ("uhat", C.c_void_p),
                 ("Cxx", C.c_void_p), ("Cuu", C.c_void_p), ("c0x", C.c_void_p), ("c0u", C.c_void_p),
-                ("cost", C.c_void_p), ("active", C.c_void_p)]
+                ("cost", C.c_void_p), ("active", C.c_void_p),
+                ("cost_model", C.c_int32), ("_pad2", C.c_int32), ("cost_par", C.c_void_p)]
 
 
 class LinearizeArgs(C.Structure):
@@ -333,7 +336,8 @@ class Kernels:
     @staticmethod
     def rollout_args(model, model_par, K, k, xhat, uhat, alphas, Qtab, ztab, seq, u_std, x_out, u_out,
                      best=None, cost_new=None, cost_all=None, x0=None, wq=None, wr=None, zx=None, lx=None,
-                     zu=None, lu=None, cost_cur=None, flags=0, status=None, active=None, q_nonzero=None):
+                     zu=None, lu=None, cost_cur=None, flags=0, status=None, active=None, q_nonzero=None,
+                     cost_model=COST_VIA, cost_par=None):
         B, N, m, n = K.shape
         L = int(alphas.shape[0])
         nvia = int(Qtab.shape[-3])
@@ -369,6 +373,7 @@ class Kernels:
         a.best, a.cost_new = _ptr(best), _ptr(_dense(cost_new, (B,), "cost_new"))
         a.x_out, a.u_out = _ptr(_dense(x_out, (B, N, n), "x_out")), _ptr(_dense(u_out, (B, N, m), "u_out"))
         a.status, a.active = _ptr(status), _ptr(active)
+        a.cost_model, a.cost_par = int(cost_model), _ptr(cost_par)
         return a
 
     @staticmethod
@@ -493,7 +498,7 @@ class Kernels:
         return self._call("admm_update", _sfx(args[0]), a, stream)
 
     def expand_quadratic(self, Qtab, ztab, seq, u_std, c0x, c0u, xhat=None, uhat=None, Cxx=None, Cuu=None,
-                         Qr=None, Rr=None, cost=None, active=None, stream=None):
+                         Qr=None, Rr=None, cost=None, active=None, cost_model=COST_VIA, cost_par=None, stream=None):
         B, N, n = c0x.shape
         m = c0u.shape[2]
         nvia = int(Qtab.shape[-3])
@@ -506,6 +511,7 @@ class Kernels:
         a.Cxx, a.Cuu = _ptr(_dense(Cxx, (B, N, n, n), "Cxx")), _ptr(_dense(Cuu, (B, N, m, m), "Cuu"))
         a.c0x, a.c0u = _ptr(_dense(c0x, (B, N, n), "c0x")), _ptr(_dense(c0u, (B, N, m), "c0u"))
         a.cost, a.active = _ptr(_dense(cost, (B,), "cost")), _ptr(active)
+        a.cost_model, a.cost_par = int(cost_model), _ptr(cost_par)
         return self._call("expand_quadratic", _sfx(c0x), a, stream)
 
     def linearize(self, model, model_par, xhat, uhat, A, Bm, active=None, stream=None):

@@ -81,6 +81,7 @@ class Engine:
         self.model_par = None
         self.Qtab = self.ztab = self.seq = self.q_nonzero = None
         self.u_std = 0.0
+        self.cost_model, self.cost_par = capi.COST_VIA, None
         self.Qr = self.Rr = self.wq = self.wr = None
         self.x_lo = self.x_hi = self.u_lo = self.u_hi = None
         self.x_sets = self.u_sets = self.x_work = self.u_work = None
@@ -107,6 +108,17 @@ class Engine:
         qnz = (self.Qtab.reshape(-1, self.Qtab.shape[-3], self.n * self.n) != 0).any(-1).any(0).cpu().numpy()
         self.q_nonzero = torch.as_tensor(qnz[seq].astype(np.int32), device=self.device)
         self.u_std = float(u_std)
+        self.cost_model, self.cost_par = capi.COST_VIA, None
+        self._outer_args = None
+
+    def set_cost_model(self, cost_model, par):
+        """Built-in non-quadratic cost of the line search and of the expansion (ISLS_COST_PHUBER: [cu, cx, px, cf, pf])."""
+        self.cost_model, self.cost_par = int(cost_model), self._t(np.ascontiguousarray(par))
+        # the via-point tables are ignored by this cost model; one all-zero entry keeps every argument block well formed
+        self.Qtab, self.ztab = torch.zeros(1, self.n, self.n, dtype=self.dtype, device=self.device), torch.zeros(1, self.n, dtype=self.dtype, device=self.device)
+        self.seq = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+        self.q_nonzero = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+        self.u_std = 0.0
         self._outer_args = None
 
     def set_nominal(self, x_nom, u_nom):
@@ -187,7 +199,8 @@ class Engine:
     # ---- single kernels -----------------------------------------------------------------------------------
     def evaluate_cost(self):
         self.kern.expand_quadratic(self.Qtab, self.ztab, self.seq, self.u_std, self.c0x, self.c0u,
-                                   xhat=self.xhat, uhat=self.uhat, cost=self.cost, stream=_stream_ptr())
+                                   xhat=self.xhat, uhat=self.uhat, cost=self.cost, cost_model=self.cost_model,
+                                   cost_par=self.cost_par, stream=_stream_ptr())
 
     def linearize(self):
         self.kern.linearize(self.model, self.model_par, self.xhat, self.uhat, self.A, self.Bm,
@@ -197,7 +210,8 @@ class Engine:
         self.kern.expand_quadratic(self.Qtab, self.ztab, self.seq, self.u_std, self.c0x, self.c0u,
                                    xhat=self.xhat, uhat=self.uhat,
                                    Cxx=self.Cxx if with_hessian else None, Cuu=self.Cuu if with_hessian else None,
-                                   Qr=self.Qr, Rr=self.Rr, active=self.outer_active, stream=_stream_ptr())
+                                   Qr=self.Qr, Rr=self.Rr, active=self.outer_active, cost_model=self.cost_model,
+                                   cost_par=self.cost_par, stream=_stream_ptr())
 
     def gain(self, active=None):
         self.kern.riccati_gain(self.A, self.Bm, self.Cxx, self.Cuu, self.K, self.Quu, self.fac, self.Qux,
@@ -215,7 +229,8 @@ class Engine:
                              self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,
                              cost_new=self.cost_new, cost_all=cost_all, wq=self.wq, wr=self.wr, zx=self.zx,
                              lx=self.lx, zu=self.zu, lu=self.lu, cost_cur=self.cost, flags=flags,
-                             status=self.status, active=active, q_nonzero=self.q_nonzero, stream=_stream_ptr())
+                             status=self.status, active=active, q_nonzero=self.q_nonzero, cost_model=self.cost_model,
+                             cost_par=self.cost_par, stream=_stream_ptr())
 
     def admm_update(self, tol_abs, tol_rel, active=None):
         self.kern.admm_update(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
@@ -257,7 +272,7 @@ class Engine:
                             self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,
                             cost_new=self.cost_new, wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx, zu=self.zu,
                             lu=self.lu, cost_cur=self.cost, flags=0, status=self.status, active=self.admm_active,
-                            q_nonzero=self.q_nonzero)
+                            q_nonzero=self.q_nonzero, cost_model=self.cost_model, cost_par=self.cost_par)
         admm = K.admm_args(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
                            x_lo=self.x_lo, x_hi=self.x_hi, u_lo=self.u_lo, u_hi=self.u_hi, relax=self.relax,
                            tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=self.admm_active,

@@ -56,10 +56,16 @@ class iSLS(Base):
 
     @cost_function.setter
     def cost_function(self, function):
-        if function is not None:
-            raise NotImplementedError("only the via-point quadratic cost (set_cost_variables) has a device "
-                                      "implementation in this round; custom cost callbacks are 'next' (SURVEY 8f-2)")
-        self._cost_function = None
+        """None -> the via-point quadratic cost of set_cost_variables; an `isls.costs` object (PseudoHuber) -> that cost
+        on the device, for the line search and for the expansion (the reference's cost_function / get_Cs pair)."""
+        if function is None:
+            self._cost_function = None
+            return
+        if not hasattr(function, "cost_model"):
+            raise NotImplementedError("cost_function must be an isls.costs object (PseudoHuber): the line search evaluates "
+                                      "the cost inside a HIP kernel and cannot call back into Python")
+        self._cost_function = function
+        self.engine.set_cost_model(function.cost_model, function.params())
 
     @property
     def AB(self):
@@ -225,9 +231,7 @@ class iSLS(Base):
             if not (is_dynamics_linear and i > 0):
                 self._linearize(get_AB)
             Cts = cts = None
-            if get_Cs is not None:
-                raise NotImplementedError("get_Cs needs a matching device cost for the line search; only the via-point "
-                                          "quadratic cost is built (SURVEY 8f-2)")
+            self._check_get_Cs(get_Cs)
             ok, _, _ = self.iterate_once_dp(max_line_search=max_line_search_iter, verbose=verbose, Cts=Cts, cts=cts,
                                             _linearized=True)
             cur = np.atleast_1d(np.array(self.cost, dtype=np.float64))
@@ -246,6 +250,16 @@ class iSLS(Base):
                 break
         return None
 
+    def _check_get_Cs(self, get_Cs):
+        """get_Cs is the derivative callback of the user's cost (isls/isls.py:102).  With a built-in cost model the
+        device expands that same cost itself, so the only get_Cs that keeps the semantics is the cost object's own."""
+        if get_Cs is None:
+            return
+        if self._cost_function is None or getattr(get_Cs, "__self__", None) is not self._cost_function:
+            raise NotImplementedError("get_Cs is accepted only as `cost.get_Cs` of the isls.costs object assigned to "
+                                      "cost_function (the device expands that cost itself); arbitrary derivative "
+                                      "callbacks would need a matching device cost for the line search")
+
     def solve_ilqr(self, get_AB=None, max_ilqr_iter=100, max_line_search_iter=25, dp=True, verbose=False, **kw):
         """Notebook-era name (Car notebooks :254): iLQR with the quadratic cost set by set_cost_variables."""
         if not dp:
@@ -261,8 +275,7 @@ class iSLS(Base):
         linearise, expand, then max_admm_iter x [ff pass, line search over alphas[:max_line_search_iter] without
         acceptance test, z/lambda update] with lambda reset and z warm-started, nominal <- last x-step, and the
         stop rules |dcost| < 1e-3 / oscillation < 1e-3.  Returns the residual log of the last outer iteration."""
-        if get_Cs is not None:
-            raise NotImplementedError("ilqr_admm with get_Cs needs a device cost for the line search (SURVEY 8f-2)")
+        self._check_get_Cs(get_Cs)
         max_iter = k_max if k_max is not None else max_iter
         L = max_line_search if max_line_search is not None else max_line_search_iter
         tol = threshold if threshold is not None else tol

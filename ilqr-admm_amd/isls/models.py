@@ -128,3 +128,36 @@ class CarSimple(Model):
         A[:, 0, 3], A[:, 1, 3], A[:, 2, 3] = dt * np.cos(th), dt * np.sin(th), dt * u[..., 0]
         B[:, 2, 0], B[:, 3, 1] = dt * v, dt
         return A, B
+
+
+class TassaCar(Model):
+    """Car-parking model of notebooks/Tutorial.ipynb cell 8 (Tassa et al.): [x, y, theta, v], [front wheel angle w,
+    acceleration a], axle distance `dist`; the Jacobians the notebook takes from autograd are written out here."""
+    model_id = capi.MODEL_TASSA
+    x_dim, u_dim = 4, 2
+
+    def __init__(self, dt, dist=2.0):
+        self.dt, self.dist = float(dt), float(dist)
+
+    def params(self):
+        return np.array([self.dt, self.dist])
+
+    def __call__(self, x, u):
+        dt, d = self.dt, self.dist
+        f = dt * x[..., 3]
+        sw = np.sin(u[..., 0]) * f
+        b = (f * np.cos(u[..., 0]) + d) - np.sqrt(d * d - sw * sw)
+        return np.stack([x[..., 0] + b * np.cos(x[..., 2]), x[..., 1] + b * np.sin(x[..., 2]), x[..., 2] + np.arcsin(sw / d),
+                         x[..., 3] + u[..., 1] * dt], axis=-1)
+
+    def get_AB(self, x, u):
+        dt, d, N = self.dt, self.dist, x.shape[0]
+        f, sw, cw = dt * x[..., 3], np.sin(u[..., 0]), np.cos(u[..., 0])
+        r = np.sqrt(d * d - (sw * f) ** 2)
+        b, dbdf, dbdw = (f * cw + d) - r, cw + (sw * sw * f) / r, -f * sw + (sw * cw * f * f) / r
+        st, ct = np.sin(x[..., 2]), np.cos(x[..., 2])
+        A, B = np.tile(np.eye(4), (N, 1, 1)), np.zeros((N, 4, 2))
+        A[:, 0, 2], A[:, 1, 2] = -b * st, b * ct
+        A[:, 0, 3], A[:, 1, 3], A[:, 2, 3] = (dbdf * dt) * ct, (dbdf * dt) * st, (sw / r) * dt
+        B[:, 0, 0], B[:, 1, 0], B[:, 2, 0], B[:, 3, 1] = dbdw * ct, dbdw * st, (cw * f) / r, dt
+        return A, B

@@ -58,6 +58,17 @@ extern "C" {
                                par = [a, b0, b1] = [A[0,d], B[0,0], B[d,0]]. Same values as ISLS_MODEL_LTI on
                                those matrices (the skipped terms are exact zeros), a sixth of the multiplies */
 
+#define ISLS_MODEL_TASSA 4  /* Tassa car-parking model, n=4 m=2 ; par = [dt, d]      (notebooks/Tutorial.ipynb cell 8):
+                               f = dt v, b = f cos w + d - sqrt(d^2 - (f sin w)^2), x+ = x + b cos th, y+ = y + b sin th,
+                               th+ = th + asin(f sin w / d), v+ = v + a dt ; state [x,y,th,v], control [w,a]              */
+
+/* cost models of the line search and of the cost expansion */
+#define ISLS_COST_VIA 0     /* via-point quadratic (isls/sls_base.py:25-44): Qtab, ztab, seq, u_std                       */
+#define ISLS_COST_PHUBER 1  /* control-quadratic + pseudo-Huber state cost (notebooks/Tutorial.ipynb cell 14):
+                               sum_t [ sum_i cu_i u_ti^2 + sum_i cx_i ph(x_ti, px_i) ] + sum_i cf_i ph(x_{N-1,i}, pf_i),
+                               ph(x,p) = sqrt(x^2 + p^2) - p ; cost_par = [cu(m), cx(n), px(n), cf(n), pf(n)]
+                               (built into the kernels of ISLS_MODEL_TASSA; Qtab/ztab/seq/u_std are then ignored)         */
+
 /* rollout flags */
 #define ISLS_RO_NAN_TO_1E5 1   /* costs[isnan] = 1e5            (iterate_once_dp only, isls/isls.py:362)          */
 #define ISLS_RO_ACCEPT_TEST 2  /* accept iff cost_best < cost_cur (isls/isls.py:365-369); else nominal is kept    */
@@ -208,6 +219,9 @@ typedef struct isls_rollout_args {
     void *x_out, *u_out;
     int32_t *status;
     const int32_t *active;
+    int32_t cost_model;             /* ISLS_COST_* */
+    int32_t _pad2;
+    const void *cost_par;           /* ISLS_COST_PHUBER: [m + 4n] shared by the batch */
 } isls_rollout_args;
 
 int isls_rollout_ls_f64(const isls_rollout_args *a, void *stream);
@@ -352,6 +366,10 @@ typedef struct isls_expand_args {
     void *c0x, *c0u;                /* [B,N,n], [B,N,m] */
     void *cost;                     /* [B] nullable */
     const int32_t *active;
+    int32_t cost_model;             /* ISLS_COST_VIA: as above; ISLS_COST_PHUBER: gradient / (diagonal) Hessian of the
+                                       pseudo-Huber cost about the nominal, the get_Cs callback of Tutorial.ipynb cell 16 */
+    int32_t _pad2;
+    const void *cost_par;
 } isls_expand_args;
 
 int isls_expand_quadratic_f64(const isls_expand_args *a, void *stream);

@@ -22,6 +22,7 @@
 #define FMOD fmod
 #define SIN sin
 #define COS cos
+#define ASIN asin
 #include "isls_oracle_impl.h"
 #undef REAL
 #undef FN
@@ -30,6 +31,7 @@
 #undef FMOD
 #undef SIN
 #undef COS
+#undef ASIN
 
 #define REAL float
 #define FN(name) name##_f32
@@ -38,6 +40,7 @@
 #define FMOD fmodf
 #define SIN sinf
 #define COS cosf
+#define ASIN asinf
 #include "isls_oracle_impl.h"
 
 int oracle_set_threads(int n)

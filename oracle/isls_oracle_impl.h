@@ -304,6 +304,15 @@ static void FN(model_step)(int model, const REAL *par, int n, int m, const REAL 
         }
         for (int j = 0; j < 3; ++j) { c += xn[j]; ex += COS(c); ey += SIN(c); }
         xn[6] = ex; xn[7] = ey; xn[8] = 0;
+    } else if (model == ISLS_MODEL_TASSA) { /* notebooks/Tutorial.ipynb cell 8 */
+        const REAL dt = par[0], d = par[1];
+        const REAL f = dt * x[3];
+        const REAL sw = SIN(u[0]) * f;
+        const REAL b = (f * COS(u[0]) + d) - SQRT(d * d - sw * sw);
+        xn[0] = x[0] + b * COS(x[2]);
+        xn[1] = x[1] + b * SIN(x[2]);
+        xn[2] = x[2] + ASIN(sw / d);
+        xn[3] = x[3] + u[1] * dt;
     } else { /* car-simple, Car notebooks cell 6 */
         const REAL dt = par[0];
         xn[0] = x[0] + dt * x[3] * COS(x[2]);
@@ -338,7 +347,11 @@ static void FN(rollout_one)(const isls_rollout_args *a, int b, REAL alpha, REAL 
             u[r] = (s + alpha * k[t * m + r]) + ((absolute || !uh) ? (REAL)0 : uh[t * m + r]);
         }
         if (xs) { for (int i = 0; i < n; ++i) xs[t * n + i] = x[i]; for (int i = 0; i < m; ++i) us[t * m + i] = u[i]; }
-        if (cost && (!a->q_nonzero || a->q_nonzero[t])) {
+        if (cost && a->cost_model == ISLS_COST_PHUBER) { /* Tutorial.ipynb cell 14: running + final pseudo-Huber terms */
+            const REAL *cp = (const REAL *)a->cost_par, *cx = cp + m, *px = cx + n, *cf = px + n, *pf = cf + n;
+            for (int i = 0; i < n; ++i) cst += cx[i] * (SQRT(x[i] * x[i] + px[i] * px[i]) - px[i]);
+            if (t == N - 1) for (int i = 0; i < n; ++i) cst += cf[i] * (SQRT(x[i] * x[i] + pf[i] * pf[i]) - pf[i]);
+        } else if (cost && (!a->q_nonzero || a->q_nonzero[t])) {
             const REAL *Q = Qtab + (int64_t)a->seq[t] * n * n, *z = ztab + (int64_t)a->seq[t] * n;
             REAL d[MAXN];
             for (int i = 0; i < n; ++i) d[i] = x[i] - z[i];
@@ -381,7 +394,11 @@ int FN(oracle_rollout_ls)(const isls_rollout_args *a)
             REAL cst, ag;
             FN(rollout_one)(a, b, alpha, xs, us, &cst, &ag);
             REAL cu = 0;
-            for (int i = 0; i < N * m; ++i) cu += us[i] * (ustd * us[i]);
+            if (a->cost_model == ISLS_COST_PHUBER) {
+                const REAL *cuw = (const REAL *)a->cost_par;
+                for (int i = 0; i < N * m; ++i) cu += cuw[i % m] * (us[i] * us[i]);
+            } else
+                for (int i = 0; i < N * m; ++i) cu += us[i] * (ustd * us[i]);
             costs[l] = cst + cu;
             augs[l] = costs[l] + ag;
             if (augs[l] != augs[l]) {
@@ -513,8 +530,40 @@ int FN(oracle_expand_quadratic)(const isls_expand_args *a)
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b) {
         if (a->active && !a->active[b]) continue;
-        const REAL *Qtab = (const REAL *)a->Qtab + (int64_t)b * a->Qtab_sb, *ztab = (const REAL *)a->ztab + (int64_t)b * a->ztab_sb;
         REAL cx_sum = 0, cu_sum = 0;
+        if (a->cost_model == ISLS_COST_PHUBER) { /* what Tutorial.ipynb cell 16 gets from autograd: ph' = x/s, ph'' = p^2/s^3 */
+            const REAL *cu = (const REAL *)a->cost_par, *cx = cu + m, *px = cx + n, *cf = px + n, *pf = cf + n;
+            for (int t = 0; t < N; ++t) {
+                const REAL *xh = a->xhat ? (const REAL *)a->xhat + ((int64_t)b * N + t) * n : 0;
+                const REAL *uh = a->uhat ? (const REAL *)a->uhat + ((int64_t)b * N + t) * m : 0;
+                REAL *c0x = (REAL *)a->c0x + ((int64_t)b * N + t) * n, *c0u = (REAL *)a->c0u + ((int64_t)b * N + t) * m;
+                const REAL *Qr = a->Qr.p ? VIEW(a->Qr, b, t) : 0, *Rr = a->Rr.p ? VIEW(a->Rr, b, t) : 0;
+                for (int i = 0; i < n; ++i) {
+                    REAL x = xh ? xh[i] : (REAL)0, s1 = SQRT(x * x + px[i] * px[i]);
+                    REAL g = cx[i] * (x / s1), h = cx[i] * ((px[i] * px[i]) / (s1 * s1 * s1)), c = cx[i] * (s1 - px[i]);
+                    if (t == N - 1) {
+                        REAL s2 = SQRT(x * x + pf[i] * pf[i]);
+                        g += cf[i] * (x / s2); h += cf[i] * ((pf[i] * pf[i]) / (s2 * s2 * s2)); c += cf[i] * (s2 - pf[i]);
+                    }
+                    c0x[i] = g; cx_sum += c;
+                    if (a->Cxx) {
+                        REAL *C = (REAL *)a->Cxx + ((int64_t)b * N + t) * n * n + i * n;
+                        for (int j = 0; j < n; ++j) C[j] = (j == i ? h : (REAL)0) + (Qr ? 2 * Qr[i * n + j] : (REAL)0);
+                    }
+                }
+                for (int i = 0; i < m; ++i) {
+                    REAL uu = uh ? uh[i] : (REAL)0;
+                    c0u[i] = 2 * (cu[i] * uu); cu_sum += cu[i] * (uu * uu);
+                    if (a->Cuu) {
+                        REAL *C = (REAL *)a->Cuu + ((int64_t)b * N + t) * m * m + i * m;
+                        for (int j = 0; j < m; ++j) C[j] = (j == i ? 2 * cu[i] : (REAL)0) + (Rr ? 2 * Rr[i * m + j] : (REAL)0);
+                    }
+                }
+            }
+            if (a->cost) ((REAL *)a->cost)[b] = cx_sum + cu_sum;
+            continue;
+        }
+        const REAL *Qtab = (const REAL *)a->Qtab + (int64_t)b * a->Qtab_sb, *ztab = (const REAL *)a->ztab + (int64_t)b * a->ztab_sb;
         for (int t = 0; t < N; ++t) {
             const REAL *Q = Qtab + (int64_t)a->seq[t] * n * n, *z = ztab + (int64_t)a->seq[t] * n;
             const REAL *xh = a->xhat ? (const REAL *)a->xhat + ((int64_t)b * N + t) * n : 0;
@@ -593,6 +642,22 @@ int FN(oracle_linearize)(const isls_linearize_args *a)
                     A[6 * 9 + 3 + j] = j0 * dt; A[7 * 9 + 3 + j] = j1 * dt;
                     Bm[6 * 3 + j] = ((REAL)0.5 * j0) * (dt * dt); Bm[7 * 3 + j] = ((REAL)0.5 * j1) * (dt * dt);
                 }
+            } else if (a->model == ISLS_MODEL_TASSA) { /* Tutorial.ipynb cell 8, differentiated by hand */
+                const REAL dt = par[0], d = par[1];
+                const REAL f = dt * x[3], sw = SIN(u[0]), cw = COS(u[0]);
+                const REAL r = SQRT(d * d - (sw * f) * (sw * f));
+                const REAL bb = (f * cw + d) - r, dbdf = cw + (sw * sw * f) / r, dbdw = -f * sw + (sw * cw * f * f) / r;
+                const REAL st = SIN(x[2]), ct = COS(x[2]);
+                for (int i = 0; i < 4; ++i) A[i * 4 + i] = 1;
+                A[0 * 4 + 2] = -bb * st;
+                A[1 * 4 + 2] = bb * ct;
+                A[0 * 4 + 3] = (dbdf * dt) * ct;
+                A[1 * 4 + 3] = (dbdf * dt) * st;
+                A[2 * 4 + 3] = (sw / r) * dt;
+                Bm[0 * 2 + 0] = dbdw * ct;
+                Bm[1 * 2 + 0] = dbdw * st;
+                Bm[2 * 2 + 0] = (cw * f) / r;
+                Bm[3 * 2 + 1] = dt;
             } else {
                 const REAL dt = par[0];
                 for (int i = 0; i < 4; ++i) A[i * 4 + i] = 1;

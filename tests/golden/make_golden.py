@@ -143,12 +143,17 @@ def expansions(obj, Qr, Rr, rx, ru):
     n, m, N = obj.x_dim, obj.u_dim, obj.N
     Cts = np.zeros((N, n + m, n + m))
     cts = np.zeros((N, n + m))
+    user = getattr(obj, "_gen_get_Cs", None)                 # non-quadratic cost: the user's get_Cs callback (isls.py:102)
+    if user is not None:
+        cts, Cts = user(obj.x_nom, obj.u_nom)
+        cts, Cts = cts.copy(), Cts.copy()
     for t in range(N):
-        Q = obj.Qs[obj.seq[t]]
-        Cts[t, :n, :n] = 2 * Q
-        Cts[t, n:, n:] = 2 * obj.Rt
-        cts[t, :n] = 2 * Q.dot(obj.x_nom[t] - obj.zs[obj.seq[t]])
-        cts[t, n:] = 2 * obj.Rt.dot(obj.u_nom[t])
+        if user is None:
+            Q = obj.Qs[obj.seq[t]]
+            Cts[t, :n, :n] = 2 * Q
+            Cts[t, n:, n:] = 2 * obj.Rt
+            cts[t, :n] = 2 * Q.dot(obj.x_nom[t] - obj.zs[obj.seq[t]])
+            cts[t, n:] = 2 * obj.Rt.dot(obj.u_nom[t])
         if Qr is not None:
             Cts[t, :n, :n] += 2 * Qr[t]
             cts[t, :n] += 2 * Qr[t].dot(obj.x_nom[t] - rx[t])
@@ -661,7 +666,138 @@ def gen_sls():
         save(f"g7_sls_{tag}.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G8: Tassa car-parking problem of notebooks/Tutorial.ipynb (non-quadratic cost through get_Cs)
+# ---------------------------------------------------------------------------------------------
+def tassa_callbacks(N, dt, dist=2.0):
+    """forward_model / cost of Tutorial.ipynb cells 8 and 14 in plain numpy, and the get_AB / get_Cs the notebook takes
+    from autograd (not installed here) written out by hand; checked against central finite differences below."""
+    cu = 1e-2 * np.array([1.0, 0.01])
+    pf, cf = np.array([0.01, 0.01, 0.01, 1.0]), np.array([0.1, 0.1, 1.0, 0.3])
+    px, cx = np.array([0.1, 0.1]), 1e-3 * np.array([1.0, 1.0])
+    cf_ = np.tile(cf[None], (N, 1))
+    cf_[:-1] = 0.0
+
+    def forward_model(s_, u):
+        w, a = u[..., 0:1], u[..., 1:2]
+        x, y, o, v = s_[..., 0:1], s_[..., 1:2], s_[..., 2:3], s_[..., 3:4]
+        f_ = dt * v
+        b = f_ * np.cos(w) + dist - np.sqrt(dist ** 2 - (np.sin(w) * f_) ** 2)
+        do = np.arcsin(np.sin(w) * f_ / dist)
+        return np.concatenate([x + b * np.cos(o), y + b * np.sin(o), o + do, v + a * dt], axis=-1)
+
+    def pseudo_huber(x, p):
+        return np.sqrt(x ** 2 + p ** 2) - p
+
+    def cost_vec(x, u):
+        lu = np.sum(cu * (u ** 2), axis=-1)
+        lf = cf_ @ pseudo_huber(x[-1], pf)
+        lx = np.sum(cx * pseudo_huber(x[:, :2], px[None]), axis=-1)
+        return lf + lu + lx
+
+    def cost(x, u):
+        if x.ndim == 3:
+            costs = np.zeros(x.shape[0])
+            for i in range(x.shape[0]):
+                costs[i] = np.sum(cost_vec(x[i], u[i]), -1)
+            costs[np.isnan(costs)] = 1e6
+        else:
+            costs = np.sum(cost_vec(x, u), -1)
+        return costs
+
+    def get_AB(x, u):
+        Nn = x.shape[0]
+        f, sw, cw = dt * x[:, 3], np.sin(u[:, 0]), np.cos(u[:, 0])
+        r = np.sqrt(dist ** 2 - (sw * f) ** 2)
+        b, dbdf, dbdw = f * cw + dist - r, cw + sw ** 2 * f / r, -f * sw + sw * cw * f ** 2 / r
+        st, ct = np.sin(x[:, 2]), np.cos(x[:, 2])
+        A, B = np.tile(np.eye(4), (Nn, 1, 1)), np.zeros((Nn, 4, 2))
+        A[:, 0, 2], A[:, 1, 2] = -b * st, b * ct
+        A[:, 0, 3], A[:, 1, 3], A[:, 2, 3] = dbdf * dt * ct, dbdf * dt * st, sw / r * dt
+        B[:, 0, 0], B[:, 1, 0], B[:, 2, 0], B[:, 3, 1] = dbdw * ct, dbdw * st, cw * f / r, dt
+        return A, B
+
+    def get_Cs(x, u):
+        Nn = x.shape[0]
+        cs_, Cs_ = np.zeros((Nn, 6)), np.zeros((Nn, 6, 6))
+        s1 = np.sqrt(x[:, :2] ** 2 + px ** 2)
+        cs_[:, :2] = cx * x[:, :2] / s1
+        Cs_[:, [0, 1], [0, 1]] = cx * px ** 2 / s1 ** 3
+        s2 = np.sqrt(x[-1] ** 2 + pf ** 2)
+        cs_[-1, :4] += cf * x[-1] / s2
+        Cs_[-1, np.arange(4), np.arange(4)] += cf * pf ** 2 / s2 ** 3
+        cs_[:, 4:] = 2 * cu * u
+        Cs_[:, [4, 5], [4, 5]] = 2 * cu
+        return cs_, Cs_
+    return forward_model, cost, cost_vec, get_AB, get_Cs, dict(cu=cu, cx=np.array([cx[0], cx[1], 0, 0]), px=np.array([px[0], px[1], 1, 1]), cf=cf, pf=pf)
+
+
+def gen_tassa():
+    import contextlib
+    import io
+    N, dt = 100, 0.03
+    f, cost, cost_vec, get_AB, get_Cs, par = tassa_callbacks(N, dt)
+    rng = np.random.default_rng(5)
+    # hand-written derivatives against central finite differences (the notebook's autograd is not available)
+    xt, ut = rng.standard_normal((N, 4)) * np.array([1, 1, 1, 3.0]), rng.standard_normal((N, 2)) * np.array([0.4, 1.0])
+    A, B = get_AB(xt, ut)
+    cs_, Cs_ = get_Cs(xt, ut)
+    h = 1e-6
+    for j in range(4):
+        e = np.zeros(4); e[j] = h
+        assert np.max(np.abs((f(xt + e, ut) - f(xt - e, ut)) / (2 * h) - A[:, :, j])) < 1e-7
+        assert np.max(np.abs((cost_vec(xt + e, ut) - cost_vec(xt - e, ut)) / (2 * h) - cs_[:, j])) < 1e-7
+        g1, _ = get_Cs(xt + e, ut); g0, _ = get_Cs(xt - e, ut)
+        assert np.max(np.abs((g1 - g0)[:, :] / (2 * h) - Cs_[:, :, j])) < 1e-6
+    for j in range(2):
+        e = np.zeros(2); e[j] = h
+        assert np.max(np.abs((f(xt, ut + e) - f(xt, ut - e)) / (2 * h) - B[:, :, j])) < 1e-7
+        assert np.max(np.abs((cost_vec(xt, ut + e) - cost_vec(xt, ut - e)) / (2 * h) - cs_[:, 4 + j])) < 1e-7
+    out = dict(N=np.array(N), dt=np.array(dt), dist=np.array(2.0), fd_x=xt, fd_u=ut, fd_A=A, fd_B=B, fd_cs=cs_, fd_Cs=Cs_,
+               **{"par_" + k: v for k, v in par.items()})
+    nprob = 2
+    x0s, u0s, res = [], [], dict(cost0=[], x_nom0=[], K0=[], k0=[], cost_log=[], n_it=[], x_fin=[], u_fin=[])
+    traces = []
+    for b in range(nprob):
+        x0 = np.array([1.0, 1.0, 1.5 * np.pi, 0.0]) + (0.0 if b == 0 else 0.05) * rng.standard_normal(4)
+        u0 = rng.standard_normal((N, 2)) * 0.1
+        x0s.append(x0), u0s.append(u0)
+
+        def fresh():
+            obj = ref.iSLS(x_dim=4, u_dim=2, N=N)
+            obj.forward_model = f
+            obj.cost_function = cost
+            x_nom, u_nom = obj.get_trajectory_batch(x0, u0)
+            obj.reset()
+            obj.nominal_values = x_nom, u_nom
+            return obj
+        obj = fresh()
+        res["cost0"].append(float(obj.cost)), res["x_nom0"].append(obj.x_nom.copy())
+        obj.A, obj.B = get_AB(obj.x_nom, obj.u_nom)
+        cts, Cts = get_Cs(obj.x_nom, obj.u_nom)
+        K, k = obj.backward_pass_DP(Cts=Cts, cts=cts)
+        res["K0"].append(K), res["k0"].append(k)
+        with contextlib.redirect_stdout(io.StringIO()):
+            obj.solve(get_AB, get_Cs, max_iter=6, max_line_search_iter=40, method='dp', verbose=False)
+        cl = np.full(8, np.nan)
+        cl[:len(obj.cost_log)] = obj.cost_log
+        res["cost_log"].append(cl), res["n_it"].append(len(obj.cost_log)), res["x_fin"].append(obj.x_nom.copy()), res["u_fin"].append(obj.u_nom.copy())
+        print("tassa problem", b, "iLQR cost log", obj.cost_log)
+        # O2 with the control limits of cells 25-27 (box u1 in [-.5,.5], u2 in [-2,2], rho_u = diag(1e-1, 1e-2), 5 ADMM its)
+        obj = fresh()
+        obj._gen_get_Cs = get_Cs
+        lo, hi = np.tile([-0.5, -2.0], N), np.tile([0.5, 2.0], N)
+        tr = []
+        o2_ilqr_admm(obj, get_AB, None, lambda u: refproj.project_bound(u, lo, hi), None, np.diag([1e-1, 1e-2]), max_iter=3, L=40, J=5,
+                     relax=1.0, tol=0.0, trace=tr)
+        traces.append(tr)
+    out.update(x0=np.stack(x0s), u0=np.stack(u0s), **{k_: np.stack(v) for k_, v in res.items()})
+    pack_trace("o2", traces, 4, 2, N, 5, out)
+    save("g8_tassa.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls"]
+    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa"]
     for w in which:
-        {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections, "sls": gen_sls}[w]()
+        {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections, "sls": gen_sls,
+         "tassa": gen_tassa}[w]()

@@ -83,7 +83,7 @@ class OracleDriver:
         self.cost_log = [[] for _ in range(B)]
         # initial cost (nominal_values setter, isls/isls_base.py:80-85)
         self.kern.expand_quadratic(pa["Qtab"], pa["ztab"], pa["seq"], pa["u_std"], self.c0x, self.c0u,
-                                   xhat=self.xhat, uhat=self.uhat, cost=self.cost)
+                                   xhat=self.xhat, uhat=self.uhat, cost=self.cost, **self.cost_kw())
         for b in range(B):
             self.cost_log[b].append(float(self.cost[b]))
 
@@ -92,7 +92,7 @@ class OracleDriver:
         self.kern.linearize(pa["model"], pa["model_par"], self.xhat, self.uhat, self.A, self.Bm)
         self.kern.expand_quadratic(pa["Qtab"], pa["ztab"], pa["seq"], pa["u_std"], self.c0x, self.c0u,
                                    xhat=self.xhat, uhat=self.uhat, Cxx=self.Cxx, Cuu=self.Cuu,
-                                   Qr=self.Qr, Rr=self.Rr)
+                                   Qr=self.Qr, Rr=self.Rr, **self.cost_kw())
 
     def gain(self):
         self.kern.riccati_gain(self.A, self.Bm, self.Cxx, self.Cuu, self.K, self.Quu, self.fac, self.Qux,
@@ -110,7 +110,13 @@ class OracleDriver:
                              pa["Qtab"], pa["ztab"], pa["seq"], pa["u_std"], self.xx, self.xu,
                              best=self.best, cost_new=self.cost_new, cost_all=cost_all,
                              wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
-                             cost_cur=self.cost, flags=flags, status=self.status, active=self.admm_active)
+                             cost_cur=self.cost, flags=flags, status=self.status, active=self.admm_active, **self.cost_kw())
+
+    def cost_kw(self):
+        """cost-model keywords (ISLS_COST_PHUBER problems carry pa['cost_model'], pa['cost_par'])."""
+        if "cost_model" not in self.pa:
+            return {}
+        return dict(cost_model=self.pa["cost_model"], cost_par=self.pa["cost_par"])
 
     def set_args(self):
         """(x_sets descriptor, x_col0, x_work) keyword arguments of admm_args for the ConvexSets state constraint."""
@@ -156,7 +162,8 @@ class OracleDriver:
         ro = K.rollout_args(pa["model"], pa["model_par"], self.K, self.k, self.xhat, self.uhat, alphas,
                             pa["Qtab"], pa["ztab"], pa["seq"], pa["u_std"], self.xx, self.xu, best=self.best,
                             cost_new=self.cost_new, wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx,
-                            zu=self.zu, lu=self.lu, cost_cur=self.cost, status=self.status, active=self.admm_active)
+                            zu=self.zu, lu=self.lu, cost_cur=self.cost, status=self.status, active=self.admm_active,
+                            **self.cost_kw())
         admm = K.admm_args(self.xx, self.xu, self.res, zx=self.zx, lx=self.lx, zu=self.zu, lu=self.lu,
                            x_lo=pa.get("x_lo") if self.zx is not None else None,
                            x_hi=pa.get("x_hi") if self.zx is not None else None,
@@ -224,3 +231,18 @@ class OracleDriver:
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+
+
+def tassa_arrays(g, bsel, dtype=np.float64):
+    """problem_arrays for the Tassa car-parking golden case (tests/golden/g8_tassa.npz): model ISLS_MODEL_TASSA, cost
+    ISLS_COST_PHUBER, nominal = open-loop rollout of the recorded u0 from x0 (the notebook's get_trajectory_batch)."""
+    bsel = list(bsel)
+    N = int(g["N"])
+    d = dict(B=len(bsel), N=N, n=4, m=2, model=capi.MODEL_TASSA, u_std=0.0,
+             model_par=np.array([float(g["dt"]), float(g["dist"])], dtype=dtype),
+             Qtab=np.zeros((1, 4, 4), dtype=dtype), ztab=np.zeros((1, 4), dtype=dtype), seq=np.zeros(N, dtype=np.int32),
+             cost_model=capi.COST_PHUBER,
+             cost_par=np.concatenate([g["par_cu"], g["par_cx"], g["par_px"], g["par_cf"], g["par_pf"]]).astype(dtype),
+             xhat=np.ascontiguousarray(g["x_nom0"][bsel]).astype(dtype), uhat=np.ascontiguousarray(g["u0"][bsel]).astype(dtype),
+             u_lo=np.tile(np.array([-0.5, -2.0], dtype=dtype), (N, 1)), u_hi=np.tile(np.array([0.5, 2.0], dtype=dtype), (N, 1)))
+    return d

@@ -296,3 +296,21 @@ def test_config5_sls_admm_kernels(oracle, golden, tag):
     hip.sls_closed_loop(dev(g["A"]), dev(g["B"]), dev(g["K"][0]), dev(g["k"][0]), dev(g["mc_x0"][0]), xl, ul)
     torch.cuda.synchronize()
     assert np.max(np.abs(xl.cpu().numpy() - g["mc_x"][0])) < 1e-9 and np.max(np.abs(ul.cpu().numpy() - g["mc_u"][0])) < 1e-8
+
+
+def test_tassa_all_kernels(dual, golden):
+    """ISLS_MODEL_TASSA + ISLS_COST_PHUBER (Tutorial.ipynb car-parking problem) kernel by kernel against the oracle: iLQR
+    iterations with 40 candidates, then iLQR-ADMM with the notebook's control limits."""
+    from helpers import tassa_arrays
+    g = golden("g8_tassa.npz")
+    dk = dual(tol=1e-9, ff_nseg=3)
+    dk.int_exact = False
+    d = OracleDriver(dk, tassa_arrays(g, [0, 1, 0]), project_u=False)
+    for it in range(3):
+        d.linearize_expand()
+        d.gain(), d.ff()
+        d.rollout(40, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST, cost_all=np.zeros((3, 40)))
+        d.xhat[:], d.uhat[:], d.cost[:] = d.xx, d.xu, d.cost_new
+    d = OracleDriver(dk, tassa_arrays(g, [0, 1]), rho_u=np.diag([1e-1, 1e-2]))
+    d.run(2, 40, 5, 0.0)
+    _report(dk)

@@ -281,3 +281,34 @@ def test_sls_config5_api(golden):
             one.AB = [g["A"], g["B"]]
             xl, ul = one.get_trajectory_sls(g["mc_x0"][1], g["K"][1], g["k"][1])
             assert rel(xl, g["mc_x"][1]) < 1e-9 and rel(ul, g["mc_u"][1]) < 1e-9
+
+
+def test_tassa_car_parking_api(golden):
+    """notebooks/Tutorial.ipynb through the class surface: TassaCar model, PseudoHuber cost, `solve(get_AB, get_Cs)` and
+    `ilqr_admm(get_Cs=..., project_u=box)` against the reference run on the notebook's own callbacks."""
+    from isls import Box, costs, iSLS, models
+    g = golden("g8_tassa.npz")
+    N = int(g["N"])
+    cost = costs.PseudoHuber(g["par_cu"], g["par_cx"], g["par_px"], g["par_cf"], g["par_pf"])
+    mdl = models.TassaCar(float(g["dt"]), float(g["dist"]))
+    # host versions of the callbacks agree with the reference-side ones
+    A, B = mdl.get_AB(g["fd_x"], g["fd_u"])
+    cs, Cs = cost.get_Cs(g["fd_x"], g["fd_u"])
+    assert rel(A, g["fd_A"]) < 1e-13 and rel(B, g["fd_B"]) < 1e-13 and rel(cs, g["fd_cs"]) < 1e-13 and rel(Cs, g["fd_Cs"]) < 1e-13
+
+    def fresh():
+        s = iSLS(4, 2, N, batch=2)
+        s.forward_model = mdl
+        s.cost_function = cost
+        s.nominal_values = g["x_nom0"], g["u0"]
+        return s
+    s = fresh()
+    assert rel(s.cost, g["cost0"]) < 1e-12 and rel(cost(g["x_nom0"], g["u0"]), g["cost0"]) < 1e-12
+    s.solve(get_Cs=cost.get_Cs, max_iter=6, max_line_search_iter=40, method='dp')
+    assert rel(s.cost, g["cost_log"][:, 6]) < 1e-7 and rel(s.x_nom, g["x_fin"]) < 1e-5 and rel(s.u_nom, g["u_fin"]) < 1e-5
+    s = fresh()
+    s.ilqr_admm(get_Cs=cost.get_Cs, project_u=Box(np.array([-0.5, -2.0]), np.array([0.5, 2.0])), max_iter=3,
+                max_line_search_iter=40, max_admm_iter=5, rho_u=np.diag([1e-1, 1e-2]), tol=0.0)
+    _check_final(s, g, "o2", [0, 1], 3, 5, {k: 1e-7 for k in ("xx", "xu", "K", "cost")})
+    with pytest.raises(NotImplementedError):
+        s.solve(get_Cs=lambda x, u: None)

@@ -476,3 +476,44 @@ def test_config5_sls_admm_matches_reference(oracle, golden, tag):
     oracle.sls_closed_loop(g["A"], g["B"], np.ascontiguousarray(g["K"][0]), np.ascontiguousarray(g["k"][0]),
                            np.ascontiguousarray(g["mc_x0"][0]), xl, ul)
     assert rel_err(xl, g["mc_x"][0]) < 1e-9 and rel_err(ul, g["mc_u"][0]) < 1e-9
+
+
+# ---- Tassa car-parking problem (notebooks/Tutorial.ipynb): non-quadratic cost through get_Cs ----------------------------
+def test_tassa_model_and_cost(oracle, golden):
+    """ISLS_MODEL_TASSA / ISLS_COST_PHUBER in the oracle against the reference run on the notebook's callbacks: Jacobians,
+    cost gradient / Hessian, nominal cost, the first backward pass, the iLQR cost log and the O2 trace."""
+    from helpers import tassa_arrays
+    from isls import _capi as capi
+    g = golden("g8_tassa.npz")
+    N = int(g["N"])
+    par = np.array([float(g["dt"]), float(g["dist"])])
+    cpar = np.concatenate([g["par_cu"], g["par_cx"], g["par_px"], g["par_cf"], g["par_pf"]])
+    x, u = np.ascontiguousarray(g["fd_x"][None]), np.ascontiguousarray(g["fd_u"][None])
+    A, Bm = np.zeros((1, N, 4, 4)), np.zeros((1, N, 4, 2))
+    oracle.linearize(capi.MODEL_TASSA, par, x, u, A, Bm)
+    assert rel_err(A[0], g["fd_A"]) < 1e-13 and rel_err(Bm[0], g["fd_B"]) < 1e-13
+    c0x, c0u, Cxx, Cuu, cost = np.zeros((1, N, 4)), np.zeros((1, N, 2)), np.zeros((1, N, 4, 4)), np.zeros((1, N, 2, 2)), np.zeros(1)
+    oracle.expand_quadratic(np.zeros((1, 4, 4)), np.zeros((1, 4)), np.zeros(N, dtype=np.int32), 0.0, c0x, c0u, xhat=x, uhat=u,
+                            Cxx=Cxx, Cuu=Cuu, cost=cost, cost_model=capi.COST_PHUBER, cost_par=cpar)
+    assert rel_err(c0x[0], g["fd_cs"][:, :4]) < 1e-13 and rel_err(c0u[0], g["fd_cs"][:, 4:]) < 1e-13
+    assert rel_err(Cxx[0], g["fd_Cs"][:, :4, :4]) < 1e-13 and rel_err(Cuu[0], g["fd_Cs"][:, 4:, 4:]) < 1e-13
+    # nominal cost, first backward pass, iLQR iterations (iterate_once_dp: 40 candidates, NaN rule, acceptance test)
+    d = OracleDriver(oracle, tassa_arrays(g, [0, 1]), project_u=False)
+    assert rel_err(d.cost, g["cost0"]) < 1e-12
+    d.linearize_expand()
+    d.gain(), d.ff()
+    assert rel_err(d.K, g["K0"]) < 1e-9 and rel_err(d.k, g["k0"]) < 1e-9
+    logs = [d.cost.copy()]
+    for it in range(6):
+        d.linearize_expand()
+        d.gain(), d.ff()
+        d.rollout(40, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST)
+        d.xhat[:], d.uhat[:], d.cost[:] = d.xx, d.xu, d.cost_new
+        logs.append(d.cost.copy())
+    logs = np.stack(logs, 1)
+    assert rel_err(logs, g["cost_log"][:, :7]) < 1e-8
+    assert rel_err(d.xhat, g["x_fin"]) < 1e-6 and rel_err(d.uhat, g["u_fin"]) < 1e-6
+    # O2 with the notebook's control limits
+    d = OracleDriver(oracle, tassa_arrays(g, [0, 1]), rho_u=np.diag([1e-1, 1e-2]))
+    tr = d.run(3, 40, 5, 0.0)
+    check_trace(tr, g, "o2", 2, floor=1e-8)
