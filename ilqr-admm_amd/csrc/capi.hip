@@ -95,12 +95,14 @@ using namespace isls;
     ISLS_API int isls_##name##_f64(const args_t *a, void *stream)                          \
     {                                                                                      \
         if (!a) return ISLS_ERR_ARG;                                                       \
+        if (a->B == 0) return ISLS_OK; /* empty batch: nothing to check, nothing to do */  \
         ScopedTimer tm(kind, (hipStream_t)stream);                                         \
         return launcher<double>(*a, (hipStream_t)stream);                                  \
     }                                                                                      \
     ISLS_API int isls_##name##_f32(const args_t *a, void *stream)                          \
     {                                                                                      \
         if (!a) return ISLS_ERR_ARG;                                                       \
+        if (a->B == 0) return ISLS_OK;                                                     \
         ScopedTimer tm(kind, (hipStream_t)stream);                                         \
         return launcher<float>(*a, (hipStream_t)stream);                                   \
     }
@@ -113,18 +115,22 @@ DEFINE_ENTRY(admm_update, isls_admm_args, launch_admm, 3)
 
 ISLS_API int isls_expand_quadratic_f64(const isls_expand_args *a, void *stream)
 {
+    if (a && a->B == 0) return ISLS_OK;
     return a ? launch_expand<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
 ISLS_API int isls_expand_quadratic_f32(const isls_expand_args *a, void *stream)
 {
+    if (a && a->B == 0) return ISLS_OK;
     return a ? launch_expand<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
 ISLS_API int isls_linearize_f64(const isls_linearize_args *a, void *stream)
 {
+    if (a && a->B == 0) return ISLS_OK;
     return a ? launch_linearize<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
 ISLS_API int isls_linearize_f32(const isls_linearize_args *a, void *stream)
 {
+    if (a && a->B == 0) return ISLS_OK;
     return a ? launch_linearize<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
 ISLS_API int isls_project_rows_f64(const isls_project_args *a, void *stream)
@@ -155,10 +161,12 @@ ISLS_API int isls_sls_closed_loop_f32(int32_t M, int32_t N, int32_t n, int32_t m
 }
 ISLS_API int isls_accept_step_f64(const isls_accept_args *a, void *stream)
 {
+    if (a && a->B == 0) return ISLS_OK;
     return a ? launch_accept<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
 ISLS_API int isls_accept_step_f32(const isls_accept_args *a, void *stream)
 {
+    if (a && a->B == 0) return ISLS_OK;
     return a ? launch_accept<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
 ISLS_API int isls_reduce_convergence_f64(int32_t B, const void *cost, const void *res, const int32_t *active,

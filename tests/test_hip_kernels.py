@@ -314,3 +314,29 @@ def test_tassa_all_kernels(dual, golden):
     d = OracleDriver(dk, tassa_arrays(g, [0, 1]), rho_u=np.diag([1e-1, 1e-2]))
     d.run(2, 40, 5, 0.0)
     _report(dk)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_degenerate_horizons_and_empty_batch(dual, N):
+    """Shortest horizons (N = 1: no recursion step at all; N = 2, 3: shorter than every prefetch ring) and an empty batch
+    through every kernel of the outer iteration."""
+    cfg = P.config2(batch=8, N=N, seed=3)
+    pa = problem_arrays(cfg, range(5))
+    for nseg in (1, 4):
+        dk = dual(ff_nseg=nseg)
+        dk.int_exact = False
+        d = OracleDriver(dk, pa, rho_u=cfg["rho_u"], relax=cfg["relax"])
+        d.run(2, 20, 2, 0.0)
+    # B = 0: the entry points return ISLS_OK without looking at the (null) pointers of empty arrays
+    import torch
+    from dual import hip_kernels
+    hip = hip_kernels()
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")     # noqa: E731
+    zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device="cuda")      # noqa: E731
+    n, m = 6, 3
+    A, Bm = z(0, N, n, n), z(0, N, n, m)
+    K, Quu, fac, Qux, k = z(0, N, m, n), z(0, N, m, m), z(0, N, m, m), z(0, N, m, n), z(0, N, m)
+    hip.riccati_gain(A, Bm, z(0, N, n, n), z(0, N, m, m), K, Quu, fac, Qux, status=zi(0))
+    hip.riccati_ff(A, Bm, z(0, N, n), z(0, N, m), K, Quu, fac, Qux, k)
+    hip.admm_update(z(0, N, n), z(0, N, m), z(0, 2), zu=z(0, N, m), lu=z(0, N, m), u_lo=z(N, m), u_hi=z(N, m))
+    torch.cuda.synchronize()
