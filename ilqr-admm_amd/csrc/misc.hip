@@ -351,10 +351,10 @@ template int launch_accept<float>(const isls_accept_args &, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // out5 = { sum cost, max prim, max dual, #active, #status!=0 } over the local shard (single workgroup)
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_kernel(int B, const T *cost, const T *res, const int32_t *active,
+__global__ __launch_bounds__(1024) void reduce_kernel(int B, const T *cost, const T *res, const int32_t *active,
                                                      const int32_t *status, T *out5)
 {
-    __shared__ T sm[5][4];
+    __shared__ T sm[5][16];                                   // one partial per wavefront of the 1024-thread workgroup
     T cs = T(0), pm = T(0), dm = T(0), na = T(0), nf = T(0);
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         if (cost) cs += cost[b];
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(int B, const T *cost, const
     __syncthreads();
     if (threadIdx.x == 0) {
         T o0 = T(0), o1 = T(0), o2 = T(0), o3 = T(0), o4 = T(0);
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < (int)(blockDim.x / kWave); ++i) {
             o0 += sm[0][i]; o3 += sm[3][i]; o4 += sm[4][i];
             o1 = sm[1][i] > o1 ? sm[1][i] : o1;
             o2 = sm[2][i] > o2 ? sm[2][i] : o2;
@@ -382,7 +382,8 @@ int launch_reduce(int32_t B, const void *cost, const void *res, const int32_t *a
                   void *out5, hipStream_t s)
 {
     if (B < 0 || !out5) return ISLS_ERR_ARG;
-    hipLaunchKernelGGL((reduce_kernel<T>), dim3(1), dim3(256), 0, s, (int)B, (const T *)cost, (const T *)res, active,
+    // latency-bound (5 small loads per trajectory): the widest workgroup keeps the dependent iterations short
+    hipLaunchKernelGGL((reduce_kernel<T>), dim3(1), dim3(B > 256 ? 1024 : 256), 0, s, (int)B, (const T *)cost, (const T *)res, active,
                        status, (T *)out5);
     return check_launch();
 }
