@@ -24,8 +24,18 @@
 
 namespace isls {
 
-constexpr int kFfDepth = 4;     // steps of operands in flight per lane (sequential form, <= 1 wave per SIMD)
-constexpr int kFfSegDepth = 2;  // ... in the time-parallel form, where kFfSegOcc co-resident waves hide the latency
+#ifndef ISLS_FF_DEPTH
+#define ISLS_FF_DEPTH 4
+#define ISLS_FF_GROUP 2
+#endif
+#ifndef ISLS_FF_SEG_DEPTH
+#define ISLS_FF_SEG_DEPTH 2
+#define ISLS_FF_SEG_GROUP 2
+#endif
+constexpr int kFfDepth = ISLS_FF_DEPTH;         // steps of operands in flight per lane (sequential form, <= 1 wave per SIMD)
+constexpr int kFfGroup = ISLS_FF_GROUP;         // ... fetched in groups of this many consecutive steps
+constexpr int kFfSegDepth = ISLS_FF_SEG_DEPTH;  // ... in the time-parallel form, where kFfSegOcc co-resident waves hide the latency
+constexpr int kFfSegGroup = ISLS_FF_SEG_GROUP;
 #ifndef ISLS_FF_SEG_OCC
 #define ISLS_FF_SEG_OCC 2
 #endif
@@ -46,7 +56,7 @@ struct FfP {
 // D = steps of operands in flight per lane, OCC = wavefronts per SIMD the register budget must allow: the
 // sequential form runs <= 1 wave per SIMD and hides HBM latency with a deep ring; the segmented form has
 // nseg times the waves and trades ring depth for co-residency.
-template <typename T, int NX, int NU, int D, int OCC>
+template <typename T, int NX, int NU, int D, int OCC, int FG>
 __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, MAXTPW = kWave / G;
@@ -201,7 +211,14 @@ __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
 #pragma unroll
             for (int j = 0; j < NX; ++j) row_now[j] = g.rrow[j];
             slot_sync();
-            fetch(t - D > t_lo ? t - D : t_lo, g);                 // refill this ring entry (clamped, unconditional)
+            // refill: FG consecutive steps at once, on the last ring entry of each group of FG -- one burst of FG steps
+            // per stream instead of FG separate requests (tools/streambench.hip: 3.8 -> 4.7 TB/s for FG = 4)
+            if constexpr (FG == 1) {
+                fetch(t - D > t_lo ? t - D : t_lo, g);             // (clamped, unconditional)
+            } else if ((d % FG) == FG - 1) {
+#pragma unroll
+                for (int q = FG - 1; q >= 0; --q) fetch(t + q - D > t_lo ? t + q - D : t_lo, ring[d - q >= 0 ? d - q : 0]);
+            }
 
             // q_i = c_i + ([A B]' v)_i        (isls.py:285-286)
             const T ci = reg_grad(c0_now, row_now);
@@ -300,9 +317,9 @@ int launch_ff(const isls_ff_args &a, hipStream_t s)
         p.tpw = pick_tpw(a.B, kWave / (NX_ + NU_), "ISLS_FF_TPW");                                     \
         const int grid = (a.B + p.tpw - 1) / p.tpw;                                                    \
         if (segmented)                                                                                 \
-            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfSegDepth, kFfSegOcc>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
+            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfSegDepth, kFfSegOcc, kFfSegGroup>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
         else                                                                                           \
-            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth, 1>), dim3(grid), dim3(64), 0, s, p);  \
+            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth, 1, kFfGroup>), dim3(grid), dim3(64), 0, s, p);  \
     }
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
