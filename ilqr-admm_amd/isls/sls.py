@@ -161,15 +161,23 @@ class SLS(Base):
         B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
         px, pu = self._projection(project_x, n), self._projection(project_u, m)
         for p_ in (px, pu):
-            if p_ is not None and not isinstance(p_, Box):
-                raise NotImplementedError("ADMM_LQT_DP on the device needs box constraints (projections.Box or a callable "
-                                          "that is recognisably a box); other sets are 'next' (SURVEY 8f-4)")
+            if p_ is not None and not isinstance(p_, (Box, ConvexSets)):
+                raise NotImplementedError("ADMM_LQT_DP runs its projections on the device: pass a projections.Box (or a "
+                                          "callable that is recognisably a box) or a projections.ConvexSets")
         Qr, Rr = self.compute_Rr_Qr(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None, dp=True)
         self.solve_dp(Rr=Rr, Qr=Qr, xr=np.zeros(N * n), ur=np.zeros(N * m))
-        if px is not None:
-            e.x_lo, e.x_hi = (e._t(v) for v in px.bounds(N, n))
-        if pu is not None:
-            e.u_lo, e.u_hi = (e._t(v) for v in pu.bounds(N, m))
+        sets = {}
+        for blk, p_, d in (("x", px, n), ("u", pu, m)):
+            if isinstance(p_, Box):
+                lo, hi = (e._t(v) for v in p_.bounds(N, d))
+                setattr(e, blk + "_lo", lo), setattr(e, blk + "_hi", hi)
+            elif isinstance(p_, ConvexSets):                    # project_set_convex over the time steps (ISLS_PROJ_SETS)
+                work = torch.zeros(B, N, d, dtype=e.dtype, device=e.device)
+                dsets = [{k: (e._t(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+                         for st in p_.sets]
+                desc = capi.Kernels.project_args(work, work, dsets, rho=p_.rho, max_iter=p_.max_iter, threshold=p_.threshold,
+                                                 cols=p_.cols)
+                sets.update({blk + "_sets": desc, blk + "_col0": p_.cols[0], blk + "_work": work})
         x0t = e._t(self._batched(x0, 1))
         one = torch.ones(1, dtype=e.dtype, device=e.device)
         stream = torch.cuda.current_stream().cuda_stream
@@ -188,10 +196,10 @@ class SLS(Base):
                                   e.xx, e.xu, x0=x0t, flags=capi.RO_ABSOLUTE, q_nonzero=e.q_nonzero,
                                   active=e.admm_active, stream=stream)
                 e.kern.admm_update(e.xx, e.xu, e.res, zx=e.zx, lx=e.lx, zu=e.zu, lu=e.lu,
-                                   x_lo=e.x_lo if px is not None else None, x_hi=e.x_hi if px is not None else None,
-                                   u_lo=e.u_lo if pu is not None else None, u_hi=e.u_hi if pu is not None else None,
+                                   x_lo=e.x_lo if isinstance(px, Box) else None, x_hi=e.x_hi if isinstance(px, Box) else None,
+                                   u_lo=e.u_lo if isinstance(pu, Box) else None, u_hi=e.u_hi if isinstance(pu, Box) else None,
                                    relax=alpha, tol_abs=tol, tol_rel=tol, res_prev=e.res_prev, active=e.admm_active,
-                                   iters=e.admm_iters, stream=stream)
+                                   iters=e.admm_iters, stream=stream, **sets)
                 buf[j].copy_(e.res)
             done = (e.admm_iters - iters_before).cpu().numpy()
             bh = buf.cpu().numpy()

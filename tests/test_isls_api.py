@@ -312,3 +312,21 @@ def test_tassa_car_parking_api(golden):
     _check_final(s, g, "o2", [0, 1], 3, 5, {k: 1e-7 for k in ("xx", "xu", "K", "cost")})
     with pytest.raises(NotImplementedError):
         s.solve(get_Cs=lambda x, u: None)
+
+
+def test_admm_lqt_dp_with_convex_sets(golden):
+    """`SLS.ADMM_LQT_DP` with a `ConvexSets` control constraint (ISLS_PROJ_SETS): a single box set through
+    project_set_convex must land on the same solution as the plain box projection."""
+    import sys
+    from isls import SLS
+    pj = sys.modules["isls.projections"]
+    c = P.config1(50)
+    outs = []
+    for proj in (pj.Box(-5.0, 5.0),
+                 pj.ConvexSets(1, (0, 1), [dict(kind=pj.SET_BOX, dim=1, A=np.eye(1), b=np.zeros(1), par=np.array([-5.0, 5.0]))],
+                               rho=1.0, max_iter=200, threshold=1e-10)):
+        s = SLS(2, 1, 50)
+        s.AB = [c["A"], c["B"]]
+        s.set_quadratic_cost(c["zs"], c["Qs"], c["seq"], c["u_std"])
+        outs.append(s.ADMM_LQT_DP(np.zeros(2), project_u=proj, max_iter=300, rho_u=c["rho_u"], tol=1e-6))
+    assert rel(outs[0][1], outs[1][1]) < 1e-6 and np.max(np.abs(outs[1][1])) < 5.0 + 1e-4
