@@ -153,6 +153,7 @@ def main():
         dt = float(tt.item())
 
     red_host = red.cpu().numpy()
+    hess_shared = bool(eng._shared_hessian())
 
     # ---- the same workload with A,B shared over batch and time (stride-0 views; SURVEY 8(d): "report both") ----
     lti_it_per_s = None
@@ -210,6 +211,8 @@ def main():
             "config": {"workload": "config2: 3-D double integrator iLQR-ADMM (DP form), box constraint on u",
                        "batch_per_gpu": B, "horizon": N, "x_dim": n, "u_dim": m, "admm_iters_J": J,
                        "line_search_L": L, "layout": "LTI stride-0 A,B" if args.lti else "time-varying A,B per trajectory",
+                       "cost_hessians": ("batch-shared [N,n,n] / [N,m,m] tables written once (via-point cost with a shared Q and rho; "
+                                         "SURVEY 8d: Cxx,Cuu terms dropped)" if hess_shared else "per trajectory [B,N,n,n]"),
                        "early_exit": False, "lti_stride0_layout_iterations_per_s": lti_it_per_s,
                        "ff_time_parallel_segments": max(1, int(eng._outer_args.ff.seg.nseg)), "trajectory_iterations_per_s": it_per_s * B,
                        "admm_iterations_per_s": it_per_s * J},

@@ -82,6 +82,7 @@ class Engine:
         self.Qtab = self.ztab = self.seq = self.q_nonzero = None
         self.u_std = 0.0
         self.cost_model, self.cost_par = capi.COST_VIA, None
+        self.allow_shared_hessian = True                      # front ends that write Cxx / Cuu themselves switch it off
         self.Qr = self.Rr = self.wq = self.wr = None
         self.x_lo = self.x_hi = self.u_lo = self.u_hi = None
         self.x_sets = self.u_sets = self.x_work = self.u_work = None
@@ -110,6 +111,7 @@ class Engine:
         self.u_std = float(u_std)
         self.cost_model, self.cost_par = capi.COST_VIA, None
         self._outer_args = None
+        self._hess_dirty = True
 
     def set_cost_model(self, cost_model, par):
         """Built-in non-quadratic cost of the line search and of the expansion (ISLS_COST_PHUBER: [cu, cx, px, cf, pf])."""
@@ -175,6 +177,7 @@ class Engine:
         self.zu, self.lu = (z(B, N, m), z(B, N, m)) if has_u else (None, None)
         self.relax = float(relax)
         self._outer_args = None
+        self._hess_dirty = True
 
         def device_sets(cs, d):
             """ConvexSets -> (isls_project_args descriptor, first column, scratch) with the operands on the device."""
@@ -206,15 +209,42 @@ class Engine:
         self.kern.linearize(self.model, self.model_par, self.xhat, self.uhat, self.A, self.Bm,
                             active=self.outer_active, stream=_stream_ptr())
 
+    def _shared_hessian(self):
+        """True when the cost Hessians are the same arrays for every trajectory of the batch: via-point cost with a batch-
+        shared Q table and batch-shared ADMM weights (Cxx_t = 2 Q_seq[t] + 2 Qr_t does not depend on the nominal).  They
+        are then written once as [N,n,n] / [N,m,m] and handed to the gain pass with a zero batch stride (SURVEY 8(d):
+        "drop the Cxx,Cuu terms when they are shared tables"), instead of B identical copies."""
+        return (self.allow_shared_hessian and self.B > 1 and self.cost_model == capi.COST_VIA
+                and self.Qtab is not None and self.Qtab.ndim == 3
+                and (self.Qr is None or self.Qr.ndim <= 3) and (self.Rr is None or self.Rr.ndim <= 3))
+
+    def hessians(self):
+        """(Cxx, Cuu) operands of the gain pass: the batch-shared [1,N,.,.] pair when the cost allows it (expand() then
+        writes that form), else the per-trajectory arrays."""
+        if not self._shared_hessian():
+            return self.Cxx, self.Cuu
+        if getattr(self, "_Cxx_sh", None) is None:
+            z = lambda *sh: torch.zeros(*sh, dtype=self.dtype, device=self.device)   # noqa: E731
+            self._Cxx_sh, self._Cuu_sh = z(1, self.N, self.n, self.n), z(1, self.N, self.m, self.m)
+            self._c0_sh = (z(1, self.N, self.n), z(1, self.N, self.m))
+        return self._Cxx_sh, self._Cuu_sh
+
     def expand(self, with_hessian=True):
+        shared = with_hessian and self._shared_hessian()
         self.kern.expand_quadratic(self.Qtab, self.ztab, self.seq, self.u_std, self.c0x, self.c0u,
                                    xhat=self.xhat, uhat=self.uhat,
-                                   Cxx=self.Cxx if with_hessian else None, Cuu=self.Cuu if with_hessian else None,
+                                   Cxx=self.Cxx if with_hessian and not shared else None,
+                                   Cuu=self.Cuu if with_hessian and not shared else None,
                                    Qr=self.Qr, Rr=self.Rr, active=self.outer_active, cost_model=self.cost_model,
                                    cost_par=self.cost_par, stream=_stream_ptr())
+        if shared and getattr(self, "_hess_dirty", True):       # constants of the problem: written once per cost / weights
+            Cxx, Cuu = self.hessians()
+            self._hess_dirty = False
+            self.kern.expand_quadratic(self.Qtab, self.ztab[:1] if self.ztab.ndim == 3 else self.ztab, self.seq, self.u_std,
+                                       *self._c0_sh, Cxx=Cxx, Cuu=Cuu, Qr=self.Qr, Rr=self.Rr, stream=_stream_ptr())
 
     def gain(self, active=None):
-        self.kern.riccati_gain(self.A, self.Bm, self.Cxx, self.Cuu, self.K, self.Quu, self.fac, self.Qux,
+        self.kern.riccati_gain(self.A, self.Bm, *self.hessians(), self.K, self.Quu, self.fac, self.Qux,
                                Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active,
                                stream=_stream_ptr())
 
@@ -263,7 +293,7 @@ class Engine:
     def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None, ff_nseg=None):
         """Marshal the argument block of isls_ilqr_admm_outer once; it stays valid while buffers are not re-allocated."""
         K = capi.Kernels
-        gain = K.gain_args(self.A, self.Bm, self.Cxx, self.Cuu, self.K, self.Quu, self.fac, self.Qux, Cux=self.Cux,
+        gain = K.gain_args(self.A, self.Bm, *self.hessians(), self.K, self.Quu, self.fac, self.Qux, Cux=self.Cux,
                            solve_mode=self.solve_mode, status=self.status, active=self.admm_active)
         ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                        Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,

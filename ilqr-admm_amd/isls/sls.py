@@ -35,6 +35,7 @@ class SLS(Base):
     def __init__(self, x_dim, u_dim, N, batch=1, dtype=np.float64, device="cuda"):
         super().__init__(x_dim, u_dim, N, batch=batch, dtype=dtype, device=device)
         self.engine.solve_mode = capi.SOLVE_INV
+        self.engine.allow_shared_hessian = False               # _expand_abs writes the per-trajectory Cxx / Cuu itself
         self._model = None
         self._Sw = self._Su = None
         self.l_side_invs = None
