@@ -63,6 +63,9 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
             if ((rc = launch_ff_prepare<T>(pr, s)) != ISLS_OK) return rc;
         }
     }
+    // element-wise ADMM updates ride on the winner replay of the rollout (one launch and one pass over x, u less)
+    const bool fuse = rollout_can_fuse_admm(a.ro, a.admm);
+    bool fused = false;
     for (int j = 0; j < a.J; ++j) {
         {
             ScopedTimer tm(1, s);
@@ -70,9 +73,9 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
         }
         {
             ScopedTimer tm(2, s);
-            if ((rc = launch_rollout<T>(a.ro, s)) != ISLS_OK) return rc;
+            if ((rc = launch_rollout<T>(a.ro, s, fuse ? &a.admm : nullptr, &fused)) != ISLS_OK) return rc;
         }
-        {
+        if (!fused) {
             ScopedTimer tm(3, s);
             if ((rc = launch_admm<T>(a.admm, s)) != ISLS_OK) return rc;
         }

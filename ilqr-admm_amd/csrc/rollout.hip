@@ -39,6 +39,14 @@ struct RoP {
     const int32_t *active;
     int cost_model;
     const T *cpar;                 // ISLS_COST_PHUBER parameters [NU + 4 NX]
+    // z / dual update of the ADMM (isls_admm_update semantics, admm.hip) fused into the winner replay by the outer
+    // driver: the winner lanes hold x_t, u_t in registers, so the update costs two reads and two writes per element and
+    // saves a launch and a second pass over x, u
+    int fa_on, fa_proj_x, fa_proj_u;
+    T fa_relax, fa_tol_abs, fa_tol_rel;
+    T *fa_zx, *fa_lx, *fa_zu, *fa_lu, *fa_res, *fa_res_prev;
+    View<T> fa_xlo, fa_xhi, fa_ulo, fa_uhi;
+    int32_t *fa_active, *fa_iters;
 };
 
 // ---- built-in forward models -------------------------------------------------
@@ -432,6 +440,17 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
             for (int j = 0; j < NX; ++j) xo[j] = accept ? xw[j] : xh[j];
 #pragma unroll
             for (int r = 0; r < NU; ++r) uo[r] = accept ? u[r] : uh[r];
+            if (p.fa_on) {                                     // hand x_t, u_t to the fused ADMM sweep through the (now dead)
+                const int uoff = p.fa_zx ? N * NX : 0;         // checkpoint area: [N][NX] (if constrained) then [N][NU]
+                if (p.fa_zx) {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) ck[t * NX + j] = xw[j];
+                }
+                if (p.fa_zu) {
+#pragma unroll
+                    for (int r = 0; r < NU; ++r) ck[uoff + t * NU + r] = u[r];
+                }
+            }
             T xn[NX];
             model.step(xw, u, xn);
 #pragma unroll
@@ -439,6 +458,64 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
             Kp += NU * NX; kp += NU; xo += NX; uo += NU;
             if (xhp) xhp += NX;
             if (uhp) uhp += NU;
+        }
+    }
+    if (p.fa_on) {
+        // Fused ADMM update (isls_admm_update semantics, admm.py:43-85): the slot's lanes sweep the flat [N*d] blocks,
+        // x / u from LDS, z / lambda / bounds coalesced from HBM -- independent iterations, no per-step round trip.
+        slot_sync();
+        T prim = T(0), dual = T(0);
+        for (int blk = 0; blk < 2; ++blk) {
+            const bool isx = blk == 0;
+            T *zz = isx ? p.fa_zx : p.fa_zu, *ll = isx ? p.fa_lx : p.fa_lu;
+            if (zz == nullptr) continue;                       // uniform
+            const int d = isx ? NX : NU, cnt = N * d, proj = isx ? p.fa_proj_x : p.fa_proj_u;
+            const T *src = isx ? ck : ck + (p.fa_zx ? N * NX : 0);
+            const View<T> &lo = isx ? p.fa_xlo : p.fa_ulo, &hi = isx ? p.fa_xhi : p.fa_uhi;
+            T p2 = T(0), d2 = T(0);
+            if (valid && c < GL) {
+                const int64_t o = bN * d;
+                for (int e = c; e < cnt; e += GL) {
+                    const T xv = src[e], zp = zz[o + e], lv = ll[o + e];
+                    const T arg = (p.fa_relax * xv + (T(1) - p.fa_relax) * zp) + lv;
+                    T zn = arg;
+                    if (proj == ISLS_PROJ_BOX) {
+                        const int t = e / d, i = e - t * d;
+                        const T lo_v = lo.at(b, t)[i], hi_v = hi.at(b, t)[i];
+                        zn = arg < lo_v ? lo_v : arg;
+                        zn = zn > hi_v ? hi_v : zn;
+                    }
+                    const T rr = xv - zn;
+                    ll[o + e] = lv + rr;
+                    zz[o + e] = zn;
+                    p2 += rr * rr;
+                    d2 += (zn - zp) * (zn - zp);
+                }
+            }
+            if (c < GL) { c_aug[c] = p2; c_pln[c] = d2; }
+            slot_sync();
+            T sp = T(0), sd = T(0);
+            for (int l = 0; l < GL; ++l) { sp += c_aug[l]; sd += c_pln[l]; }
+            slot_sync();
+            prim += sqrt(sp);
+            dual += sqrt(sd);
+        }
+        if (valid && c == 0) {
+            T *res = p.fa_res + (int64_t)b * 2;
+            T *prev = p.fa_res_prev ? p.fa_res_prev + (int64_t)b * 2 : nullptr;
+            if (p.fa_active && prev) {
+                bool stop = false;
+                if (prim < p.fa_tol_abs && dual < p.fa_tol_abs) stop = true;
+                else {
+                    const T pc = fabs(prev[0] - prim) / (prev[0] + T(1e-30));
+                    const T dc = fabs(prev[1] - dual) / (prev[1] + T(1e-30));
+                    stop = pc < p.fa_tol_rel && dc < p.fa_tol_rel;
+                }
+                if (stop) p.fa_active[b] = 0;
+            }
+            res[0] = prim; res[1] = dual;
+            if (prev) { prev[0] = prim; prev[1] = dual; }
+            if (p.fa_iters) p.fa_iters[b] += 1;
         }
     }
 #ifdef ISLS_DIAG
@@ -449,8 +526,9 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
 }
 
 template <typename T>
-int launch_rollout(const isls_rollout_args &a, hipStream_t s)
+int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_args *fused, bool *did_fuse)
 {
+    if (did_fuse) *did_fuse = false;
     if (a.B < 0 || a.N < 1 || a.L < 1 || a.L > 64) return ISLS_ERR_ARG;
     if (!a.model_par || !a.K || !a.k || !a.alphas || !a.x_out || !a.u_out) return ISLS_ERR_ARG;
     if (a.cost_model == ISLS_COST_VIA && (!a.Qtab || !a.ztab || !a.seq)) return ISLS_ERR_ARG;
@@ -489,8 +567,24 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s)
     while (nseg > 1 && smem_bytes(nseg) > 20 * 1024) --nseg;   // <= 20 KB per wavefront keeps 8 workgroups per CU
     p.seg_len = (a.N + nseg - 1) / nseg;
     p.nseg = (a.N + p.seg_len - 1) / p.seg_len;                // drop empty trailing segments
+    p.fa_on = 0;
+    p.fa_zx = p.fa_lx = p.fa_zu = p.fa_lu = p.fa_res = p.fa_res_prev = nullptr;
+    p.fa_active = p.fa_iters = nullptr;
+    p.fa_proj_x = p.fa_proj_u = 0;
+    p.fa_relax = p.fa_tol_abs = p.fa_tol_rel = T(0);
     const size_t smem = smem_bytes(p.nseg);
     if (smem > 64 * 1024) return ISLS_ERR_UNSUPPORTED;
+    // the fused ADMM sweep takes x_t, u_t through the checkpoint area of the slot: [N][n] + [N][m] words must fit
+    if (fused && (int64_t)a.N * ((fused->zx ? a.n : 0) + (fused->zu ? a.m : 0)) > (int64_t)(a.L + 1) * p.nseg * a.n) fused = nullptr;
+    if (fused) {                                               // validated by the caller (rollout_can_fuse_admm)
+        if (did_fuse) *did_fuse = true;
+        const isls_admm_args &f = *fused;
+        p.fa_on = 1; p.fa_proj_x = f.proj_x; p.fa_proj_u = f.proj_u;
+        p.fa_relax = (T)f.relax; p.fa_tol_abs = (T)f.tol_abs; p.fa_tol_rel = (T)f.tol_rel;
+        p.fa_zx = (T *)f.zx; p.fa_lx = (T *)f.lx; p.fa_zu = (T *)f.zu; p.fa_lu = (T *)f.lu;
+        p.fa_xlo = View<T>(f.x_lo); p.fa_xhi = View<T>(f.x_hi); p.fa_ulo = View<T>(f.u_lo); p.fa_uhi = View<T>(f.u_hi);
+        p.fa_res = (T *)f.res; p.fa_res_prev = (T *)f.res_prev; p.fa_active = f.active; p.fa_iters = f.iters;
+    }
 #define LAUNCH_G(NX_, NU_, MODEL_, G_) \
     hipLaunchKernelGGL((rollout_kernel<T, NX_, NU_, MODEL_, G_>), dim3(grid), dim3(64), smem, s, p)
 #define LAUNCH(NX_, NU_, MODEL_)                                     \
@@ -514,7 +608,20 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s)
 #undef LAUNCH_G
     return check_launch();
 }
-template int launch_rollout<double>(const isls_rollout_args &, hipStream_t);
-template int launch_rollout<float>(const isls_rollout_args &, hipStream_t);
+template int launch_rollout<double>(const isls_rollout_args &, hipStream_t, const isls_admm_args *, bool *);
+template int launch_rollout<float>(const isls_rollout_args &, hipStream_t, const isls_admm_args *, bool *);
+
+// The ADMM update can ride on the winner replay when it is the plain element-wise form (no set projections), works
+// on the arrays this rollout writes, shares its active mask and no acceptance test can keep the old nominal.
+bool rollout_can_fuse_admm(const isls_rollout_args &r, const isls_admm_args &a)
+{
+    if (r.flags & (ISLS_RO_ACCEPT_TEST | ISLS_RO_ABSOLUTE)) return false;
+    if (a.B != r.B || a.N != r.N || a.n != r.n || a.m != r.m || !a.res) return false;
+    if (a.xx != r.x_out || a.xu != r.u_out || a.active != r.active) return false;
+    if ((a.zx && a.proj_x == ISLS_PROJ_SETS) || (a.zu && a.proj_u == ISLS_PROJ_SETS)) return false;
+    if (a.zx && (!a.lx || (a.proj_x == ISLS_PROJ_BOX && (!a.x_lo.p || !a.x_hi.p)))) return false;
+    if (a.zu && (!a.lu || (a.proj_u == ISLS_PROJ_BOX && (!a.u_lo.p || !a.u_hi.p)))) return false;
+    return true;
+}
 
 }  // namespace isls
