@@ -330,3 +330,36 @@ def test_admm_lqt_dp_with_convex_sets(golden):
         s.set_quadratic_cost(c["zs"], c["Qs"], c["seq"], c["u_std"])
         outs.append(s.ADMM_LQT_DP(np.zeros(2), project_u=proj, max_iter=300, rho_u=c["rho_u"], tol=1e-6))
     assert rel(outs[0][1], outs[1][1]) < 1e-6 and np.max(np.abs(outs[1][1])) < 5.0 + 1e-4
+
+
+def test_headline_size_properties(monkeypatch):
+    """BASELINE.json's full size (B = 4096, N = 100, n = 6, m = 3, fp64) through size-independent properties:
+    batch invariance (a trajectory solved inside the 4096-batch equals the same trajectory solved in a batch of 5, bit for
+    bit: slots never interact), the consensus variable is inside the box exactly, every cost is finite and below the
+    initial one, no status bit is raised, and the ADMM primal residual does not grow over the inner iterations."""
+    from isls import Box
+    # the engine picks the number of time-parallel feed-forward segments from the batch size (3 at B >= 4096, else 4), which
+    # changes the association of a few sums; with the same segmentation the results are bit-identical
+    monkeypatch.setenv("ISLS_FF_NSEG", "3")
+    B = 4096
+    cfg = P.config2(batch=B, N=100, seed=0)
+    box = Box(cfg["u_lo"], cfg["u_hi"])
+    kw = dict(max_iter=3, max_line_search_iter=20, max_admm_iter=5, rho_u=cfg["rho_u"], alpha=cfg["relax"], tol=0.0)
+    big = make_isls(cfg, range(B))
+    c0 = np.array(big.cost, dtype=np.float64).copy()
+    logs = big.ilqr_admm(project_u=box, log=True, **kw)
+    sel = [0, 1, 777, 2048, 4095]
+    small = make_isls(cfg, sel)
+    small.ilqr_admm(project_u=box, **kw)
+    e, es = big.engine, small.engine
+    for name in ("xhat", "uhat", "K", "k", "zu", "lu", "cost"):
+        a, b_ = getattr(e, name)[sel].cpu().numpy(), getattr(es, name).cpu().numpy()
+        assert np.array_equal(a, b_), name
+    zu = e.zu.cpu().numpy()
+    assert np.all(zu >= cfg["u_lo"]) and np.all(zu <= cfg["u_hi"])
+    c1 = np.array(big.cost, dtype=np.float64)
+    assert np.all(np.isfinite(c1)) and np.all(c1 < c0) and not e.status.cpu().numpy().any()
+    lg = np.stack(logs)                                            # [J, B, 2] of the last outer iteration
+    assert lg.shape == (5, B, 2) and np.all(np.isfinite(lg)) and np.all(lg >= 0)
+    act = lg[0, :, 0] > 1e-9                                       # trajectories whose control bound is active at all
+    assert act.any() and np.median(lg[-1, act, 0]) <= np.median(lg[0, act, 0])
