@@ -1,9 +1,9 @@
-// riccati.hip -- backward Riccati pass on gfx950: gain pass and feed-forward pass.
+// riccati.hip -- backward Riccati pass on gfx950: the gain pass (the feed-forward pass is riccati_ff.hip).
 //
-// Reference semantics: iSLS.backward_pass_DP (isls/isls.py:229-308), SLS.solve_dp / solve_dp_ff
-// (isls/sls.py:85-202).  See include/isls_hip.h for the exact formulas and array formats.
+// Reference semantics: the K / V half of iSLS.backward_pass_DP (isls/isls.py:229-308) and of SLS.solve_dp
+// (isls/sls.py:85-166).  See include/isls_hip.h for the exact formulas and array formats.
 //
-// Mapping (both kernels): one 64-lane wavefront per workgroup, cut into TPW = 64/(n+m) slots of
+// Mapping: one 64-lane wavefront per workgroup, cut into TPW = 64/(n+m) slots of
 // G = n+m lanes; slot s owns trajectory blockIdx.x*TPW + s.  Lane i of a slot owns ROW i of the
 // stacked (n+m) x (n+m) matrix [Qxx Qxu; Qux Quu] = C + [A B]' V [A B]:
 //     S_i  = sum_k [A B][k,i] * V[k,:]          (row i of [A B]'V,   n FMAs x n)
@@ -21,7 +21,6 @@
 namespace isls {
 
 constexpr int kGainDepth = 4;   // steps of A,B,C in flight per lane in the gain pass
-constexpr int kFfDepth = 4;     // steps of operands in flight per lane in the feed-forward pass
 
 // ================================================================================================
 // Gain pass
