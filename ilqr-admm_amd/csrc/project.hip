@@ -81,7 +81,7 @@ int launch_project(const isls_project_args &a, hipStream_t s)
     const bool direct = a.nsets == 1 && a.sets[0].A == nullptr;
     for (int i = 0; i < a.nsets; ++i) {
         const isls_cset &c = a.sets[i];
-        if (c.kind != ISLS_SET_BOX && c.kind != ISLS_SET_SOC_UNIT && c.kind != ISLS_SET_SQUARE) return ISLS_ERR_UNSUPPORTED;
+        if (c.kind < ISLS_SET_BOX || c.kind > ISLS_SET_QUADRATIC) return ISLS_ERR_UNSUPPORTED;
         if (c.dim < 1 || c.dim > kMaxSetDim) return ISLS_ERR_ARG;
         if (!direct && (!c.A || !c.b)) return ISLS_ERR_ARG;
         if (c.kind != ISLS_SET_SOC_UNIT && !c.par) return ISLS_ERR_ARG;

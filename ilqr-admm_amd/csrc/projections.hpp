@@ -5,6 +5,8 @@
 //   ISLS_SET_SOC_UNIT  (z,t) -> ||z|| <= t, project_soc_unit_batch          isls/projections.py:140-162
 //   ISLS_SET_SQUARE    l <= ||W(y[:q]-c)||_inf <= u on the first q entries  isls/projections.py:256-266 and the
 //                      keep-out rectangles of notebooks/Car/Iterative LQR with state constraints.ipynb cell 18
+//   ISLS_SET_LINEAR    l <= a'y <= u, project_linear_batch                  isls/projections.py:30-43
+//   ISLS_SET_QUADRATIC l <= y'y/2 <= u, project_quadratic_batch            isls/projections.py:91-105
 //   project_set_convex                                                      isls/projections.py:289-374
 // Every array of a row lives in registers: all loops run to the compile-time maxima with constant indices and
 // are predicated on the runtime dimension (a runtime index into a per-lane array would go to scratch memory).
@@ -50,7 +52,6 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
         const bool cond2 = (zn > t) || (zn > -t);
         const bool cond3 = zn <= t;
         const T tmp = (zn + t) / T(2);
-        const T sc = tmp / (zn + T(1e-30));
 #pragma unroll
         for (int i = 0; i < kMaxSetDim; ++i) {
             if (i < dim) {
@@ -62,7 +63,41 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
                 v[i] = o;
             }
         }
-        (void)sc;
+    } else if (kind == ISLS_SET_LINEAR) {                      // par = l, u, a[dim]
+        const T l = par[0], u = par[1];
+        const T *a = par + 2;
+        T atx = T(0), ata = T(0);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < dim) { atx += v[i] * a[i]; ata += a[i] * a[i]; }
+        ata += T(1e-30);
+        const bool hi = atx > u, lo = atx < l;
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < dim) {
+                const T tmp = a[i] / ata;
+                T o = v[i];
+                if (hi) o = o - (atx - u) * tmp;
+                if (lo) o = o - (atx - l) * tmp;
+                v[i] = o;
+            }
+    } else if (kind == ISLS_SET_QUADRATIC) {                   // par = l, u
+        const T l = par[0], u = par[1];
+        T ss = T(0);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < dim) ss += v[i] * v[i];
+        const T val = T(0.5) * ss, nrm = sqrt(ss);
+        const bool hi = val > u, lo = l > val;
+        const T su = sqrt(T(2) * u), sl = sqrt(T(2) * l);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < dim) {
+                T o = v[i];
+                if (hi) o = v[i] * su / nrm;
+                if (lo) o = v[i] * sl / nrm;
+                v[i] = o;
+            }
     } else if (kind == ISLS_SET_SQUARE) {                      // par = q, l, u, c[q], W[q*q], Winv[q*q]
         const int q = (int)par[0];
         const T l = par[1], u = par[2];

@@ -155,7 +155,7 @@ EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             "isls_timing_read_ms"]
 
 
-SET_BOX, SET_SOC_UNIT, SET_SQUARE = 1, 2, 3
+SET_BOX, SET_SOC_UNIT, SET_SQUARE, SET_LINEAR, SET_QUADRATIC = 1, 2, 3, 4, 5
 MAX_ROW_DIM, MAX_SET_DIM, MAX_SETS = 4, 5, 4
 
 

@@ -35,7 +35,7 @@ class Box:
         return expand(self.lo), expand(self.hi)
 
 
-SET_BOX, SET_SOC_UNIT, SET_SQUARE = 1, 2, 3     # include/isls_hip.h ISLS_SET_*
+SET_BOX, SET_SOC_UNIT, SET_SQUARE, SET_LINEAR, SET_QUADRATIC = 1, 2, 3, 4, 5     # include/isls_hip.h ISLS_SET_*
 
 
 class ConvexSets:
@@ -62,6 +62,10 @@ class ConvexSets:
             return lambda v: project_bound(v, par[:d], par[d:2 * d])
         if kind == SET_SOC_UNIT:
             return project_soc_unit
+        if kind == SET_LINEAR:
+            return lambda v: project_linear_batch(v, np.broadcast_to(par[2:], np.shape(v)), par[0], par[1])
+        if kind == SET_QUADRATIC:
+            return lambda v: project_quadratic_batch(v, par[0], par[1])
         q = int(par[0])
         l, u, c = par[1], par[2], par[3:3 + q]
         W, Wi = par[3 + q:3 + q + q * q].reshape(q, q), par[3 + q + q * q:3 + q + 2 * q * q].reshape(q, q)

@@ -246,6 +246,8 @@ int isls_rollout_ls_f32(const isls_rollout_args *a, void *stream);
 #define ISLS_SET_BOX 1       /* par: lo[dim], hi[dim]                                                  */
 #define ISLS_SET_SOC_UNIT 2  /* (z, t) = first dim-1 entries, last entry; no parameters                */
 #define ISLS_SET_SQUARE 3    /* par: q, l, u, c[q], W[q*q], Winv[q*q]: l <= ||W(y[:q]-c)||_inf <= u    */
+#define ISLS_SET_LINEAR 4    /* par: l, u, a[dim]: l <= a'y <= u        (project_linear_batch, projections.py:30-43) */
+#define ISLS_SET_QUADRATIC 5 /* par: l, u: l <= y'y/2 <= u              (project_quadratic_batch, projections.py:91-105) */
 
 typedef struct isls_cset {
     int32_t kind, dim;          /* primitive and dimension of A y + b                               */

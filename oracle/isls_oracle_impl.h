@@ -746,6 +746,30 @@ static void FN(primitive)(int kind, int dim, const REAL *par, REAL *v)
         if (cond1) for (int i = 0; i < dim; ++i) o[i] = 0;
         if (cond3) for (int i = 0; i < dim; ++i) o[i] = v[i];
         for (int i = 0; i < dim; ++i) v[i] = o[i];
+    } else if (kind == ISLS_SET_LINEAR) {     /* project_linear_batch, isls/projections.py:30-43 */
+        REAL l = par[0], u = par[1], atx = 0, ata = 0;
+        const REAL *a = par + 2;
+        for (int i = 0; i < dim; ++i) { atx += v[i] * a[i]; ata += a[i] * a[i]; }
+        ata += (REAL)1e-30;
+        int hi = atx > u, lo = atx < l;
+        for (int i = 0; i < dim; ++i) {
+            REAL tmp = a[i] / ata, o = v[i];
+            if (hi) o = o - (atx - u) * tmp;
+            if (lo) o = o - (atx - l) * tmp;
+            v[i] = o;
+        }
+    } else if (kind == ISLS_SET_QUADRATIC) {  /* project_quadratic_batch, isls/projections.py:91-105 */
+        REAL l = par[0], u = par[1], ss = 0;
+        for (int i = 0; i < dim; ++i) ss += v[i] * v[i];
+        REAL val = (REAL)0.5 * ss, nrm = SQRT(ss);
+        int hi = val > u, lo = l > val;
+        REAL su = SQRT(2 * u), sl = SQRT(2 * l);
+        for (int i = 0; i < dim; ++i) {
+            REAL o = v[i];
+            if (hi) o = v[i] * su / nrm;
+            if (lo) o = v[i] * sl / nrm;
+            v[i] = o;
+        }
     } else if (kind == ISLS_SET_SQUARE) {
         int q = (int)par[0];
         REAL l = par[1], u = par[2];

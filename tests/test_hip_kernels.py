@@ -245,6 +245,13 @@ def test_projection_kernels(oracle, golden):
     par = np.concatenate([[2, 1.0, 2.5], [0.2, -0.1], np.eye(2).ravel(), np.eye(2).ravel()])
     o, _, h, _ = _dual_project(oracle, sq, [dict(kind=capi.SET_SQUARE, dim=2, par=par)])
     assert np.max(np.abs(o - h)) < 1e-15
+    qd = np.ascontiguousarray(np.stack([g["quad_in"], 2.0 * g["quad_in"]]))
+    o, _, h, _ = _dual_project(oracle, qd, [dict(kind=capi.SET_QUADRATIC, dim=3, par=np.array([0.5, 3.0]))])
+    assert np.max(np.abs(o - h)) < 1e-14
+    lin = np.ascontiguousarray(g["lin_in"][:, None, :])
+    par = np.ascontiguousarray(np.concatenate([np.tile([-0.5, 1.0], (50, 1)), g["lin_a"]], axis=1))
+    o, _, h, _ = _dual_project(oracle, lin, [dict(kind=capi.SET_LINEAR, dim=3, par=par)])
+    assert np.max(np.abs(o - h)) < 1e-14 and np.allclose(h[:, 0], g["lin_out"], atol=1e-13)
     # chance-constraint rows: two SOC images, A_i, b_i differ per problem (variance / bound per problem)
     P, R = 9, 50
     A0 = np.tile(g["setcvx_A0"][None], (P, 1, 1)) * (1 + 0.2 * rng.random((P, 1, 1)))

@@ -517,3 +517,17 @@ def test_tassa_model_and_cost(oracle, golden):
     d = OracleDriver(oracle, tassa_arrays(g, [0, 1]), rho_u=np.diag([1e-1, 1e-2]))
     tr = d.run(3, 40, 5, 0.0)
     check_trace(tr, g, "o2", 2, floor=1e-8)
+
+
+def test_linear_and_quadratic_projections_match_reference(oracle, golden):
+    """ISLS_SET_LINEAR / ISLS_SET_QUADRATIC direct forms == project_linear_batch / project_quadratic_batch of the reference
+    (per-row `a` of the linear golden case = one problem per row with its own parameter block)."""
+    from isls import _capi as capi
+    g = golden("g6_projections.npz")
+    q = np.ascontiguousarray(g["quad_in"][None])
+    out, _ = _proj(oracle, q, [dict(kind=capi.SET_QUADRATIC, dim=3, par=np.array([0.5, 3.0]))])
+    assert np.allclose(out[0], g["quad_out"], rtol=0, atol=1e-15)
+    lin = np.ascontiguousarray(g["lin_in"][:, None, :])                     # 50 problems x 1 row
+    par = np.concatenate([np.tile([-0.5, 1.0], (50, 1)), g["lin_a"]], axis=1)
+    out, _ = _proj(oracle, lin, [dict(kind=capi.SET_LINEAR, dim=3, par=np.ascontiguousarray(par))])
+    assert np.allclose(out[:, 0], g["lin_out"], rtol=0, atol=1e-14)
