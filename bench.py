@@ -82,7 +82,11 @@ def main():
     ap.add_argument("--lti", action="store_true", help="share A,B over batch and time (stride-0 views)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories in the CPU-baseline sample (0: auto)")
+    ap.add_argument("--config5", action="store_true", help="secondary workload: SLS-ADMM with chance constraints (B=8192, N=50)")
+    ap.add_argument("--config5-dim", type=int, default=1, help="double integrator dimension of the config-5 workload (1 or 3)")
     args = ap.parse_args()
+    if args.config5:
+        return config5_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -234,6 +238,82 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+# ---- config 5 (SLS-ADMM with chance constraints): secondary workload, `--config5` ----------------------------------------
+def config5_problem(B, nb_dim, N, seed=0):
+    from isls import sls_dense as dense
+    from isls.utils import get_double_integrator_AB
+    pj = sys.modules["isls.projections"]
+    rng = np.random.default_rng(seed)
+    n, m, p = 2 * nb_dim, nb_dim, nb_dim
+    A, Bm = get_double_integrator_AB(nb_dim, nb_deriv=2, dt=1.0 / N)
+    Sw, Su = dense.transfer_matrices(A, Bm, N)
+    targets = np.concatenate([rng.uniform(0.5, 1.5, (B, nb_dim)), np.zeros((B, nb_dim))], 1)
+    zs = np.stack([np.zeros((B, n)), targets], 1)
+    seq = np.zeros(N, dtype=np.int32); seq[N - 1] = 1
+    Q, R, xd = dense.dense_cost(zs, np.stack([np.zeros((n, n)), 1e6 * np.eye(n)]), seq, 1e-2, N, n, m)
+    rr = dense.rho_diagonal(1e2, N, m)
+    Linv, r_side = dense.admm_sls_setup(Sw, Su, Q, R, xd, rr, p, B)
+    cs = pj.chance_constraint_rows(p, rng.uniform(5.0, 8.0, B), -rng.uniform(5.0, 8.0, B), rng.uniform(0.005, 0.02, B),
+                                   1.6448536269514722)
+    return Linv, r_side, rr, cs
+
+
+def config5_run(kern, Linv, r_side, rr, cs, iters, dtype, wrap, sync):
+    mk = lambda a: wrap(np.ascontiguousarray(a, dtype=dtype))   # noqa: E731
+    sets = [{k: (mk(v) if isinstance(v, np.ndarray) else v) for k, v in st.items()} for st in cs.sets]
+    x_u = wrap(np.zeros(r_side.shape, dtype=dtype))
+    it = wrap(np.zeros(r_side.shape[0], dtype=np.int32))
+    args = (mk(Linv), mk(r_side), mk(rr), sets, x_u)
+    kw = dict(alpha=1.0, tol=0.0, rel_tol=0.0, max_iter=iters, rho=cs.rho, inner_max_iter=cs.max_iter, threshold=cs.threshold, iters=it)
+    kern.sls_admm(*args, **kw)
+    sync()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        kern.sls_admm(*args, **kw)
+        reps += 1
+        sync()
+        if time.perf_counter() - t0 > 2.0 or reps >= 20:
+            break
+    return (time.perf_counter() - t0) / reps, x_u
+
+
+def config5_main(args):
+    """`bench.py --config5`: config 5 of BASELINE.json / SURVEY 8(d) -- SLS-ADMM with SOC chance constraints, N=50, B=8192
+    problems that differ in target, bound and variance, fp32 and fp64.  One JSON line per precision: ADMM iterations/s over
+    the whole batch (max_iter fixed, stop rules off so the work is constant), the CPU oracle timed beside it on a sample."""
+    import isls  # noqa: F401
+    from isls.engine import kernels
+    torch.cuda.set_device(0)
+    B, N, iters = (args.batch if args.batch != 4096 else 8192), (args.horizon if args.horizon != 100 else 50), 50
+    Linv, r_side, rr, cs = config5_problem(B, args.config5_dim, N)
+    hip = kernels()
+    dev = lambda a: torch.from_numpy(a).cuda()                  # noqa: E731
+    for dtype, name in ((np.float32, "f32"), (np.float64, "f64")):
+        dt, x_u = config5_run(hip, Linv, r_side, rr, cs, iters, dtype, dev, torch.cuda.synchronize)
+        out = {"metric": "SLS-ADMM iterations/sec (config 5)", "value": iters / dt, "unit": "iterations/s", "n_gpus": 1,
+               "dtype": name, "data": "synthetic", "higher_is_better": True,
+               "config": {"workload": f"config5: DI-{args.config5_dim}D SLS-ADMM, SOC chance constraints", "batch": B, "horizon": N,
+                          "admm_iters": iters, "inner_max_iter": cs.max_iter},
+               "problems_per_s": B / dt, "ms_per_solve": 1e3 * dt}
+        if not args.no_cpu_baseline:                             # the CPU oracle, a reported baseline only
+            from oracle import oracle as orc
+            okern, olib = orc.load()
+            cores = orc.set_threads(olib, host_cores())
+            sample = min(B, 1024)
+            cs_s = type(cs)(cs.dim, cs.cols, [{k: (v[:sample] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[0] == B else v)
+                                               for k, v in st.items()} for st in cs.sets], rho=cs.rho, max_iter=cs.max_iter,
+                            threshold=cs.threshold)
+            dtc, x_c = config5_run(okern, Linv, r_side[:sample], rr, cs_s, iters, dtype, lambda a: a, lambda: None)
+            d = np.abs(x_u.cpu().numpy()[:sample].astype(np.float64) - x_c.astype(np.float64)).reshape(sample, -1).max(1)
+            d = d / np.abs(x_c.astype(np.float64)).reshape(sample, -1).max(1)
+            out["cpu_baseline"] = {"value": iters / (dtc * B / sample), "unit": "iterations/s", "cores": cores, "kind": "port",
+                                   "sample": f"{sample} problems, scaled linearly to {B}"}
+            # problems whose bound is infeasible do not contract and amplify rounding differences: median and max
+            out["rel_diff_vs_oracle_on_sample"] = {"median": float(np.median(d)), "max": float(np.max(d))}
+        print(json.dumps(out))
 
 
 def host_cores():
