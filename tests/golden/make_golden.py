@@ -473,35 +473,34 @@ def gen_arm():
 
 
 def ref_keepout_projection(N, d):
-    """project_state of notebooks/Car/Iterative LQR with state constraints.ipynb cell 18 (reference functions only)."""
-    xs_ = np.array([[-7.0, -3.0], [-3.0, -7.0]])
-    a_ = np.array([[2.0, 1.0], [2.0, 1.0]])
-    a_safe = a_ + 0.5
-    Ws = np.stack([np.diag(a_safe[0, 0] / a_safe[0]), np.diag(a_safe[1, 0] / a_safe[1])])
-    alpha = -np.pi / 4
-    Rm = np.array([[np.cos(alpha), -np.sin(alpha)], [np.sin(alpha), np.cos(alpha)]])
-    Ws = Ws @ Rm.T
-    Ws_inv = np.linalg.inv(Ws)
-    upper_sq, lower_sq = 1e5, a_safe[:, 0] / 2
+    """State constraint of the car notebook (`Iterative LQR with state constraints`, cell 18) rebuilt from the reference's
+    primitives: stay outside two rectangles (2 x 1 plus a 0.5 margin, rotated by -45 degrees, centred at (-7,-3) and
+    (-3,-7)); each rectangle is a `project_square_batch` in a scaled, rotated frame and the two are intersected by
+    `project_set_convex(rho=10, max_iter=15, threshold=1e-3)` over the N state rows.  Returns (project_x, rho_x)."""
+    centres = ((-7.0, -3.0), (-3.0, -7.0))
+    size = np.array([2.0, 1.0]) + 0.5
+    ang = -np.pi / 4
+    rot = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    frame = np.diag(size[0] / size) @ rot.T                     # rectangle -> square of half-width size[0]/2
+    frame_inv = np.linalg.inv(frame)
 
-    def make_function(i):
-        def f(y):
-            y_ = y.reshape(N, d).copy()
-            z = y_[:, :2] - xs_[i][None]
-            z_projected = refproj.project_square_batch(z @ Ws[i].T, lower_sq[i], upper_sq)
-            y_[:, :2] = z_projected @ Ws_inv[i].T + xs_[i][None]
-            return y_
-        return f
+    def keep_out(centre):
+        c = np.asarray(centre)
 
-    projections = [make_function(i) for i in range(2)]
-    As, bs = [np.eye(d)] * 2, [np.zeros(d)] * 2
+        def proj(rows):
+            out = rows.reshape(N, d).copy()
+            local = (out[:, :2] - c) @ frame.T
+            out[:, :2] = refproj.project_square_batch(local, size[0] / 2, 1e5) @ frame_inv.T + c
+            return out
+        return proj
+    parts = [keep_out(c) for c in centres]
 
-    def project_state(x):
-        x_ = x.reshape(N, d).copy()
-        return refproj.project_set_convex(x_, As, bs, projections, rho=1e1, max_iter=15, verbose=0, threshold=1e-3).flatten()
+    def project_x(flat):
+        return refproj.project_set_convex(flat.reshape(N, d).copy(), [np.eye(d)] * 2, [np.zeros(d)] * 2, parts, rho=1e1,
+                                          max_iter=15, verbose=0, threshold=1e-3).flatten()
     rho_x = np.zeros((N, d, d))
-    rho_x[:, :2, :2] = np.eye(2) * 1e-1
-    return project_state, rho_x
+    rho_x[:, 0, 0] = rho_x[:, 1, 1] = 1e-1
+    return project_x, rho_x
 
 
 def gen_car():
@@ -670,66 +669,64 @@ def gen_sls():
 # G8: Tassa car-parking problem of notebooks/Tutorial.ipynb (non-quadratic cost through get_Cs)
 # ---------------------------------------------------------------------------------------------
 def tassa_callbacks(N, dt, dist=2.0):
-    """forward_model / cost of Tutorial.ipynb cells 8 and 14 in plain numpy, and the get_AB / get_Cs the notebook takes
-    from autograd (not installed here) written out by hand; checked against central finite differences below."""
-    cu = 1e-2 * np.array([1.0, 0.01])
-    pf, cf = np.array([0.01, 0.01, 0.01, 1.0]), np.array([0.1, 0.1, 1.0, 0.3])
-    px, cx = np.array([0.1, 0.1]), 1e-3 * np.array([1.0, 1.0])
-    cf_ = np.tile(cf[None], (N, 1))
-    cf_[:-1] = 0.0
+    """Car-parking problem of Tutorial.ipynb (cells 8, 14, 16) as plain numpy callbacks for the reference solver: dynamics,
+    cost, and -- the notebook differentiates with autograd, which is not installed here -- hand-written Jacobians and cost
+    derivatives (checked against central finite differences in gen_tassa).
+      state [px, py, heading, speed], control [steer, accel];  roll = dt*speed,
+      back = roll*cos(steer) + dist - sqrt(dist^2 - (roll*sin(steer))^2),  heading += asin(roll*sin(steer)/dist)
+      cost_t = wu.u^2 + wx.H(p_xy, sx) (+ wf.H(x, sf) at the last step),  H(x,s) = sqrt(x^2 + s^2) - s"""
+    wu = 1e-2 * np.array([1.0, 0.01])
+    wx, sx = 1e-3 * np.ones(2), 0.1 * np.ones(2)
+    wf, sf = np.array([0.1, 0.1, 1.0, 0.3]), np.array([0.01, 0.01, 0.01, 1.0])
+    last = np.zeros(N)
+    last[-1] = 1.0
 
-    def forward_model(s_, u):
-        w, a = u[..., 0:1], u[..., 1:2]
-        x, y, o, v = s_[..., 0:1], s_[..., 1:2], s_[..., 2:3], s_[..., 3:4]
-        f_ = dt * v
-        b = f_ * np.cos(w) + dist - np.sqrt(dist ** 2 - (np.sin(w) * f_) ** 2)
-        do = np.arcsin(np.sin(w) * f_ / dist)
-        return np.concatenate([x + b * np.cos(o), y + b * np.sin(o), o + do, v + a * dt], axis=-1)
+    def huber(x, s):
+        return np.sqrt(x ** 2 + s ** 2) - s
 
-    def pseudo_huber(x, p):
-        return np.sqrt(x ** 2 + p ** 2) - p
+    def forward_model(x, u):
+        roll = dt * x[..., 3]
+        lat = np.sin(u[..., 0]) * roll
+        back = roll * np.cos(u[..., 0]) + dist - np.sqrt(dist ** 2 - lat ** 2)
+        return np.stack([x[..., 0] + back * np.cos(x[..., 2]), x[..., 1] + back * np.sin(x[..., 2]),
+                         x[..., 2] + np.arcsin(lat / dist), x[..., 3] + u[..., 1] * dt], axis=-1)
 
-    def cost_vec(x, u):
-        lu = np.sum(cu * (u ** 2), axis=-1)
-        lf = cf_ @ pseudo_huber(x[-1], pf)
-        lx = np.sum(cx * pseudo_huber(x[:, :2], px[None]), axis=-1)
-        return lf + lu + lx
+    def cost_vec(x, u):                                          # per-step cost of one trajectory [N]
+        terminal = last * np.sum(wf * huber(x[-1], sf))
+        return terminal + np.sum(wu * u ** 2, axis=-1) + np.sum(wx * huber(x[:, :2], sx), axis=-1)
 
-    def cost(x, u):
-        if x.ndim == 3:
-            costs = np.zeros(x.shape[0])
-            for i in range(x.shape[0]):
-                costs[i] = np.sum(cost_vec(x[i], u[i]), -1)
-            costs[np.isnan(costs)] = 1e6
-        else:
-            costs = np.sum(cost_vec(x, u), -1)
-        return costs
+    def cost(x, u):                                              # [L,N,.] candidates -> [L] (NaN -> 1e6), or one trajectory
+        if x.ndim == 2:
+            return np.sum(cost_vec(x, u))
+        c = np.array([np.sum(cost_vec(xi, ui)) for xi, ui in zip(x, u)])
+        c[np.isnan(c)] = 1e6
+        return c
 
     def get_AB(x, u):
-        Nn = x.shape[0]
-        f, sw, cw = dt * x[:, 3], np.sin(u[:, 0]), np.cos(u[:, 0])
-        r = np.sqrt(dist ** 2 - (sw * f) ** 2)
-        b, dbdf, dbdw = f * cw + dist - r, cw + sw ** 2 * f / r, -f * sw + sw * cw * f ** 2 / r
-        st, ct = np.sin(x[:, 2]), np.cos(x[:, 2])
-        A, B = np.tile(np.eye(4), (Nn, 1, 1)), np.zeros((Nn, 4, 2))
-        A[:, 0, 2], A[:, 1, 2] = -b * st, b * ct
-        A[:, 0, 3], A[:, 1, 3], A[:, 2, 3] = dbdf * dt * ct, dbdf * dt * st, sw / r * dt
-        B[:, 0, 0], B[:, 1, 0], B[:, 2, 0], B[:, 3, 1] = dbdw * ct, dbdw * st, cw * f / r, dt
+        roll, sw, cw = dt * x[:, 3], np.sin(u[:, 0]), np.cos(u[:, 0])
+        root = np.sqrt(dist ** 2 - (sw * roll) ** 2)
+        back = roll * cw + dist - root
+        d_roll, d_steer = cw + sw ** 2 * roll / root, -roll * sw + sw * cw * roll ** 2 / root
+        sh, ch = np.sin(x[:, 2]), np.cos(x[:, 2])
+        A, B = np.tile(np.eye(4), (x.shape[0], 1, 1)), np.zeros((x.shape[0], 4, 2))
+        A[:, 0, 2], A[:, 1, 2] = -back * sh, back * ch
+        A[:, 0, 3], A[:, 1, 3], A[:, 2, 3] = d_roll * dt * ch, d_roll * dt * sh, sw / root * dt
+        B[:, 0, 0], B[:, 1, 0], B[:, 2, 0], B[:, 3, 1] = d_steer * ch, d_steer * sh, cw * roll / root, dt
         return A, B
 
-    def get_Cs(x, u):
-        Nn = x.shape[0]
-        cs_, Cs_ = np.zeros((Nn, 6)), np.zeros((Nn, 6, 6))
-        s1 = np.sqrt(x[:, :2] ** 2 + px ** 2)
-        cs_[:, :2] = cx * x[:, :2] / s1
-        Cs_[:, [0, 1], [0, 1]] = cx * px ** 2 / s1 ** 3
-        s2 = np.sqrt(x[-1] ** 2 + pf ** 2)
-        cs_[-1, :4] += cf * x[-1] / s2
-        Cs_[-1, np.arange(4), np.arange(4)] += cf * pf ** 2 / s2 ** 3
-        cs_[:, 4:] = 2 * cu * u
-        Cs_[:, [4, 5], [4, 5]] = 2 * cu
-        return cs_, Cs_
-    return forward_model, cost, cost_vec, get_AB, get_Cs, dict(cu=cu, cx=np.array([cx[0], cx[1], 0, 0]), px=np.array([px[0], px[1], 1, 1]), cf=cf, pf=pf)
+    def get_Cs(x, u):                                            # gradient [N,6] and Hessian [N,6,6] per step
+        g, H = np.zeros((x.shape[0], 6)), np.zeros((x.shape[0], 6, 6))
+        r1 = np.sqrt(x[:, :2] ** 2 + sx ** 2)
+        g[:, :2] = wx * x[:, :2] / r1
+        H[:, [0, 1], [0, 1]] = wx * sx ** 2 / r1 ** 3
+        r2 = np.sqrt(x[-1] ** 2 + sf ** 2)
+        g[-1, :4] += wf * x[-1] / r2
+        H[-1, np.arange(4), np.arange(4)] += wf * sf ** 2 / r2 ** 3
+        g[:, 4:] = 2 * wu * u
+        H[:, [4, 5], [4, 5]] = 2 * wu
+        return g, H
+    par = dict(cu=wu, cx=np.array([wx[0], wx[1], 0, 0]), px=np.array([sx[0], sx[1], 1, 1]), cf=wf, pf=sf)
+    return forward_model, cost, cost_vec, get_AB, get_Cs, par
 
 
 def gen_tassa():
