@@ -194,10 +194,13 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
     const bool has_wq = p.wq.p != nullptr, has_wr = p.wr.p != nullptr;
 
     // ---- per-lane load plan for the record elements e = c + GL*j : source word(s), step stride, LDS word ---
-    // absent elements read K[b,0,0,0] with stride 0 (a valid word) and are zeroed when staged
+    // absent elements read K[b,0,0,0] with stride 0 (a valid word) and are zeroed when staged; staging is
+    //   rec = ma * fma(-mb, b, a)   with 0/1 masks: exactly a - b (one rounding), a, or 0 -- two instructions per element
+    // instead of a subtraction and four selects (the record of a non-finite K would be NaN rather than 0 in its absent
+    // entries; every control is NaN then anyway)
     const T *pa[JM], *pb[JM];
     int stp[JM], dst[JM];
-    bool has_a[JM], has_b[JM];
+    T ma[JM], mb[JM];
     static_for<JM>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const int e = c < GL ? c + GL * j : REC;               // extra idle lanes stage nothing
@@ -211,11 +214,12 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
         else if (e < O_RU) { if (has_uh) { a = p.uhat + bN * NU + (e - O_UH); st = NU; } }
         else if (e < O_WR) { if (has_wr) { a = p.zu + bN * NU + (e - O_RU); bq = p.lu + bN * NU + (e - O_RU); st = NU; } }
         else if (e < REC) { if (has_wr) { a = p.wr.at(bb, 0) + (e - O_WR); st = (int)p.wr.st; } }
-        has_a[j] = a != nullptr;
-        has_b[j] = bq != nullptr;
-        pa[j] = has_a[j] ? a : p.K + bN * NU * NX;
-        pb[j] = has_b[j] ? bq : pa[j];
-        stp[j] = has_a[j] ? st : 0;
+        const bool has_a = a != nullptr, has_b = bq != nullptr;
+        ma[j] = has_a ? T(1) : T(0);
+        mb[j] = has_b ? T(1) : T(0);
+        pa[j] = has_a ? a : p.K + bN * NU * NX;
+        pb[j] = has_b ? bq : pa[j];
+        stp[j] = has_a ? st : 0;
         dst[j] = (c < GL && e < REC) ? e : O_DUMP;
     });
     Model<T, NX, NU, MODEL> model;
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
                 T *rec = recs + (t & 1) * RECP;
 #pragma unroll
                 for (int j = 0; j < JM; ++j)                   // unconditional ds_writes (dump word for surplus); z - lambda
-                    rec[dst[j]] = has_a[j] ? (has_b[j] ? ra[d][j] - rb[d][j] : ra[d][j]) : T(0);
+                    rec[dst[j]] = ma[j] * fma(-mb[j], rb[d][j], ra[d][j]);
                 slot_sync();                                   // record(t) visible to the slot
                 RSTAMP(0)
                 {
