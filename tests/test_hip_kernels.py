@@ -347,3 +347,14 @@ def test_degenerate_horizons_and_empty_batch(dual, N):
     hip.riccati_ff(A, Bm, z(0, N, n), z(0, N, m), K, Quu, fac, Qux, k)
     hip.admm_update(z(0, N, n), z(0, N, m), z(0, 2), zu=z(0, N, m), lu=z(0, N, m), u_lo=z(N, m), u_hi=z(N, m))
     torch.cuda.synchronize()
+
+
+def test_long_horizon_car(dual):
+    """N = 500 (the horizon of the car notebooks): beyond the 256-step range of the Q_t ballot masks, 50 line-search
+    candidates, ragged time-parallel segments."""
+    cfg = P.config4(batch=8, N=500, seed=1)
+    dk = dual(ff_nseg=7)
+    dk.int_exact = False
+    d = OracleDriver(dk, problem_arrays(cfg, range(3)), rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+    d.run(2, 50, 3, 0.0)
+    _report(dk)
