@@ -39,7 +39,8 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
     constexpr int V_OFF = 0, AB_OFF = V_OFF + NX * NX, Q_OFF = AB_OFF + NX * W, K_OFF = Q_OFF + NU * W;
-    constexpr int SLOT = ((K_OFF + NU * NX) | 1);          // odd stride: slots start on different banks
+    constexpr int DUMP_OFF = K_OFF + NU * NX;              // W words that absorb the LDS writes of lanes with nothing to publish
+    constexpr int SLOT = ((DUMP_OFF + W) | 1);             // odd stride: slots start on different banks
     constexpr int JA = (NX * NX + G - 1) / G, JB = (NX * NU + G - 1) / G, JQ = (NU * W + G - 1) / G;
     __shared__ T lds[TPW * SLOT];
 
@@ -55,6 +56,16 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     const bool xl = i < NX;                                   // lane owns a row of Qxx
     const int a_row = xl ? 0 : i - NX;                        // row of [Qux Quu] for u-lanes
     const int64_t bN = (int64_t)bb * N;
+    // LDS destinations of everything a lane publishes, fixed for the whole horizon: lanes (or elements) with nothing to
+    // publish point at the dump words, so no ds_write of the step loop sits behind an exec-mask branch
+    int dA[JA], dB[JB];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) { const int e = i + G * j; dA[j] = (valid && e < NX * NX) ? AB_OFF + (e / NX) * W + (e % NX) : DUMP_OFF; }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) { const int e = i + G * j; dB[j] = (valid && e < NX * NU) ? AB_OFF + (e / NU) * W + NX + (e % NU) : DUMP_OFF; }
+    const int qdst = (!xl && valid) ? Q_OFF + a_row * W : DUMP_OFF;          // row of [Qux Quu]
+    const int kdst = (xl && valid) ? K_OFF + i : DUMP_OFF, kstr = (xl && valid) ? NX : 0;   // column i of K
+    const int vdst = (xl && valid) ? V_OFF + i * NX : DUMP_OFF;              // row i of V
 
     // ---- terminal step: K[N-1] = 0 (isls.py:245), V = Cxx[N-1] (isls.py:251/257) -----------------
     {
@@ -104,15 +115,9 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     auto step = [&](int t, Stage &g) {
         // stage [A_t B_t] into the record: row k = [A[k,:] B[k,:]]
 #pragma unroll
-        for (int j = 0; j < JA; ++j) {
-            const int e = i + G * j;
-            if (valid && e < NX * NX) ABs[(e / NX) * W + (e % NX)] = g.ra[j];
-        }
+        for (int j = 0; j < JA; ++j) rec[dA[j]] = g.ra[j];
 #pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            const int e = i + G * j;
-            if (valid && e < NX * NU) ABs[(e / NU) * W + NX + (e % NU)] = g.rb[j];
-        }
+        for (int j = 0; j < JB; ++j) rec[dB[j]] = g.rb[j];
         T c_now[W];
 #pragma unroll
         for (int j = 0; j < W; ++j) c_now[j] = (j < NX && !xl && !has_cux) ? T(0) : g.crow[j];   // Cux absent -> 0
@@ -140,11 +145,9 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         }
 #pragma unroll
         for (int c = 0; c < W; ++c) M[c] = c_now[c] + M[c];
-        // (3) u-lanes publish their row of [Qux Quu]
-        if (!xl && valid) {
+        // (3) u-lanes publish their row of [Qux Quu] (x-lanes write the dump words)
 #pragma unroll
-            for (int c = 0; c < W; ++c) Qs[a_row * W + c] = M[c];
-        }
+        for (int c = 0; c < W; ++c) rec[qdst + c] = M[c];
         slot_sync();                                          // (b)
 
         // (4) factor Quu (redundantly in every lane), solve for column i of K
@@ -180,12 +183,11 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
             }
         }
         const int64_t o = bN + t;
+#pragma unroll
+        for (int r = 0; r < NU; ++r) rec[kdst + r * kstr] = Kc[r];
         if (xl && valid) {
 #pragma unroll
-            for (int r = 0; r < NU; ++r) {
-                Ks[r * NX + i] = Kc[r];
-                p.K[(o * NU + r) * NX + i] = Kc[r];
-            }
+            for (int r = 0; r < NU; ++r) p.K[(o * NU + r) * NX + i] = Kc[r];
         }
         if (valid) {
             // cooperative store of [Qux Quu] rows
@@ -199,24 +201,25 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                     else p.Quu[(o * NU + r) * NU + (c - NX)] = v;
                 }
             }
-            // factor: row r written by lane r (values are identical in every lane)
+            // factor: row i written by lane i < NU (the values are identical in every lane; the row is picked by selects)
+            if (i < NU) {
 #pragma unroll
-            for (int r = 0; r < NU; ++r) {
-                if (i == r) {
+                for (int c = 0; c < NU; ++c) {
+                    T v = T(0);
 #pragma unroll
-                    for (int c = 0; c < NU; ++c) {
-                        T v;
-                        if (p.mode == ISLS_SOLVE_CHOL) v = (c == r) ? rd[r] : (c > r ? U[r][c] : T(0));
-                        else v = inv[r][c];
-                        p.fac[(o * NU + r) * NU + c] = v;
+                    for (int r = 0; r < NU; ++r) {
+                        const T vr = (p.mode == ISLS_SOLVE_CHOL) ? ((c == r) ? rd[r] : (c > r ? U[r][c] : T(0))) : inv[r][c];
+                        v = (i == r) ? vr : v;
                     }
+                    p.fac[(o * NU + i) * NU + c] = v;
                 }
             }
         }
         slot_sync();                                          // (c) Ks visible
 
-        // (5) V row i = Qxx + (K'Quu)K + Qux'K + K'Qux   (isls.py:300 / sls.py:153), x-lanes only
-        if (xl) {
+        // (5) V row i = Qxx + (K'Quu)K + Qux'K + K'Qux   (isls.py:300 / sls.py:153); u-lanes run the same instructions
+        // on their clamped column and write the dump words
+        {
             T Wr[NU];
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                     t3 += Kc[r] * Qs[r * W + j];               // K' Qux
                 }
                 const T vn = (p.mode == ISLS_SOLVE_CHOL) ? ((M[j] + t1) + t2) + t3 : ((M[j] + t2) + t3) + t1;
-                if (valid) Vs[i * NX + j] = vn;
+                rec[vdst + j] = vn;
             }
         }
     };
