@@ -12,7 +12,7 @@
 
 namespace isls {
 
-constexpr int kPrepDepth = 3;     // steps of operands in flight per lane (ff_prepare_kernel)
+constexpr int kPrepDepth = 2;     // steps of operands in flight per lane (ff_prepare_kernel)
 constexpr int kMaxFfSeg = 16;     // segments the stitch kernel has LDS for
 constexpr int kStitchTraj = 4;    // trajectories per stitch workgroup
 

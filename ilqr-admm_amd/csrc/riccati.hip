@@ -20,7 +20,8 @@
 
 namespace isls {
 
-constexpr int kGainDepth = 4;   // steps of A,B,C in flight per lane in the gain pass
+constexpr int kGainDepth = 2;   // steps of A,B,C in flight per lane (a step takes ~2 us, far more than an HBM round trip; deeper rings
+                                // only cost registers: D = 4 spilled into AGPRs and ran 13 % slower)
 
 // ================================================================================================
 // Gain pass

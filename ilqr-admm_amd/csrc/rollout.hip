@@ -149,7 +149,7 @@ struct Model<T, 4, 2, ISLS_MODEL_TASSA> {      // Tassa car-parking [x, y, theta
     }
 };
 
-constexpr int kRolloutDepth = 3;   // steps of record elements in flight per lane
+constexpr int kRolloutDepth = 2;   // steps of record elements in flight per lane (D = 2..5 run within 3 %: issue bound; 2 is leanest)
 constexpr int kMaxSeg = 10;        // winner replay: at most this many segments
 
 template <int NX, int NU>
