@@ -22,6 +22,7 @@ struct ExpP {
     const int32_t *active;
     int cost_model;
     const T *cpar;
+    const int32_t *qnz;
 };
 
 template <typename T>
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpP<T> p)
     // c0x[t,i] = 2 * sum_j Q_t[i,j] (xhat[t,j] - z_t[j]);   cost_x = sum d_i (Q d)_i
     for (int e = lane; e < N * n; e += kWave) {
         const int t = e / n, i = e - t * n;
+        if (p.qnz && p.qnz[t] == 0) {                          // Q_t == 0: gradient and cost term vanish, nothing to read
+            p.c0x[bN * n + e] = T(0);
+            continue;
+        }
         const T *Q = Qtab + (int64_t)p.seq[t] * n * n + i * n, *z = ztab + (int64_t)p.seq[t] * n;
         const T *xh = p.xhat ? p.xhat + (bN + t) * n : nullptr;
         T sacc = T(0);
@@ -125,7 +130,7 @@ int launch_expand(const isls_expand_args &a, hipStream_t s)
     p.xhat = (const T *)a.xhat; p.uhat = (const T *)a.uhat;
     p.Cxx = (T *)a.Cxx; p.Cuu = (T *)a.Cuu; p.c0x = (T *)a.c0x; p.c0u = (T *)a.c0u; p.cost = (T *)a.cost;
     p.active = a.active;
-    p.cost_model = a.cost_model; p.cpar = (const T *)a.cost_par;
+    p.cost_model = a.cost_model; p.cpar = (const T *)a.cost_par; p.qnz = a.q_nonzero;
     hipLaunchKernelGGL((expand_kernel<T>), dim3(a.B), dim3(64), 0, s, p);
     return check_launch();
 }

@@ -101,7 +101,7 @@ class ExpandArgs(C.Structure):
                 ("xhat", C.c_void_p), ("uhat", C.c_void_p),
                 ("Cxx", C.c_void_p), ("Cuu", C.c_void_p), ("c0x", C.c_void_p), ("c0u", C.c_void_p),
                 ("cost", C.c_void_p), ("active", C.c_void_p),
-                ("cost_model", C.c_int32), ("_pad2", C.c_int32), ("cost_par", C.c_void_p)]
+                ("cost_model", C.c_int32), ("_pad2", C.c_int32), ("cost_par", C.c_void_p), ("q_nonzero", C.c_void_p)]
 
 
 class LinearizeArgs(C.Structure):
@@ -498,7 +498,8 @@ class Kernels:
         return self._call("admm_update", _sfx(args[0]), a, stream)
 
     def expand_quadratic(self, Qtab, ztab, seq, u_std, c0x, c0u, xhat=None, uhat=None, Cxx=None, Cuu=None,
-                         Qr=None, Rr=None, cost=None, active=None, cost_model=COST_VIA, cost_par=None, stream=None):
+                         Qr=None, Rr=None, cost=None, active=None, cost_model=COST_VIA, cost_par=None, q_nonzero=None,
+                         stream=None):
         B, N, n = c0x.shape
         m = c0u.shape[2]
         nvia = int(Qtab.shape[-3])
@@ -511,7 +512,7 @@ class Kernels:
         a.Cxx, a.Cuu = _ptr(_dense(Cxx, (B, N, n, n), "Cxx")), _ptr(_dense(Cuu, (B, N, m, m), "Cuu"))
         a.c0x, a.c0u = _ptr(_dense(c0x, (B, N, n), "c0x")), _ptr(_dense(c0u, (B, N, m), "c0u"))
         a.cost, a.active = _ptr(_dense(cost, (B,), "cost")), _ptr(active)
-        a.cost_model, a.cost_par = int(cost_model), _ptr(cost_par)
+        a.cost_model, a.cost_par, a.q_nonzero = int(cost_model), _ptr(cost_par), _ptr(q_nonzero)
         return self._call("expand_quadratic", _sfx(c0x), a, stream)
 
     def linearize(self, model, model_par, xhat, uhat, A, Bm, active=None, stream=None):

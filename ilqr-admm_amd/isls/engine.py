@@ -203,7 +203,7 @@ class Engine:
     def evaluate_cost(self):
         self.kern.expand_quadratic(self.Qtab, self.ztab, self.seq, self.u_std, self.c0x, self.c0u,
                                    xhat=self.xhat, uhat=self.uhat, cost=self.cost, cost_model=self.cost_model,
-                                   cost_par=self.cost_par, stream=_stream_ptr())
+                                   cost_par=self.cost_par, q_nonzero=self.q_nonzero, stream=_stream_ptr())
 
     def linearize(self):
         self.kern.linearize(self.model, self.model_par, self.xhat, self.uhat, self.A, self.Bm,
@@ -236,7 +236,7 @@ class Engine:
                                    Cxx=self.Cxx if with_hessian and not shared else None,
                                    Cuu=self.Cuu if with_hessian and not shared else None,
                                    Qr=self.Qr, Rr=self.Rr, active=self.outer_active, cost_model=self.cost_model,
-                                   cost_par=self.cost_par, stream=_stream_ptr())
+                                   cost_par=self.cost_par, q_nonzero=self.q_nonzero, stream=_stream_ptr())
         if shared and getattr(self, "_hess_dirty", True):       # constants of the problem: written once per cost / weights
             Cxx, Cuu = self.hessians()
             self._hess_dirty = False

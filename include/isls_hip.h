@@ -372,6 +372,7 @@ typedef struct isls_expand_args {
                                        pseudo-Huber cost about the nominal, the get_Cs callback of Tutorial.ipynb cell 16 */
     int32_t _pad2;
     const void *cost_par;
+    const int32_t *q_nonzero;       /* [N] nullable hint as in isls_rollout_args: 0 where Q_t == 0 for every trajectory */
 } isls_expand_args;
 
 int isls_expand_quadratic_f64(const isls_expand_args *a, void *stream);
