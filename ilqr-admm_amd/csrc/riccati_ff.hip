@@ -56,7 +56,9 @@ struct FfP {
 // D = steps of operands in flight per lane, OCC = wavefronts per SIMD the register budget must allow: the
 // sequential form runs <= 1 wave per SIMD and hides HBM latency with a deep ring; the segmented form has
 // nseg times the waves and trades ring depth for co-residency.
-template <typename T, int NX, int NU, int D, int OCC, int FG>
+// ROWC: the ADMM weights Qr, Rr do not depend on the time step (stride 0: the usual rho * I): the lane's own weight row is
+// then loaded once instead of riding in every ring entry (NX loads and NX registers per step and entry less).
+template <typename T, int NX, int NU, int D, int OCC, int FG, bool ROWC>
 __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, MAXTPW = kWave / G;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
 
     struct Stage {
         T ra[JA], rb[JB], rk[JK], rq[JK], ruu[JU], rf[JU];
-        T c0, hv, zv, lv, rrow[NX];
+        T c0, hv, zv, lv, rrow[ROWC ? 1 : NX];
     };
     auto fetch = [&](int t, Stage &g) {
         const T *a = bA + (int64_t)t * p.A.st, *bm = bB + (int64_t)t * p.Bm.st;
@@ -146,13 +148,17 @@ __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
             g.zv = pz[e];
             g.lv = pl[e];
             g.hv = ph ? ph[e] : T(0);
-            const T *q = prow + (int64_t)t * rowst;
+            if constexpr (!ROWC) {
+                const T *q = prow + (int64_t)t * rowst;
 #pragma unroll
-            for (int j = 0; j < NX; ++j) g.rrow[j] = q[j < lim ? j : lim - 1];
+                for (int j = 0; j < NX; ++j) g.rrow[j] = q[j < lim ? j : lim - 1];
+            }
         } else {
             g.hv = g.zv = g.lv = T(0);
+            if constexpr (!ROWC) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) g.rrow[j] = T(0);
+                for (int j = 0; j < NX; ++j) g.rrow[j] = T(0);
+            }
         }
     };
     // cx_i / cu_i = c0 + 2 * (row of Qr/Rr) . d       (isls/sls.py:132-137; O2 of SURVEY 8c)
@@ -167,6 +173,11 @@ __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
         return hasreg ? c0v + T(2) * sacc : c0v;
     };
 
+    // time-invariant weights (ROWC): the lane's own row of Qr / Rr, loaded once
+    T rowc[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) rowc[j] = (ROWC && hasreg) ? prow[j < lim ? j : lim - 1] : T(0);
+
     // ---- terminal step: v = cx[N-1], k[N-1] = 0 (last segment); the others start from v_in = 0 ----------
     T vcur;
     {
@@ -174,7 +185,10 @@ __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
         fetch(N - 1, term);
         rec[D_OFF + i] = hasreg ? term.hv - (term.zv - term.lv) : T(0);
         slot_sync();
-        const T cterm = reg_grad(term.c0, term.rrow);
+        T rowt[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) rowt[j] = ROWC ? rowc[j] : term.rrow[ROWC ? 0 : j];
+        const T cterm = reg_grad(term.c0, rowt);
         vcur = last ? cterm : T(0);
         rec[xl ? V_OFF + i : DUMP_OFF] = vcur;
         if (valid && !xl && last) p.k[((int64_t)b * N + N - 1) * NU + iu] = T(0);
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
             const T c0_now = g.c0;
             T row_now[NX];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) row_now[j] = g.rrow[j];
+            for (int j = 0; j < NX; ++j) row_now[j] = ROWC ? rowc[j] : g.rrow[ROWC ? 0 : j];
             slot_sync();
             // refill: FG consecutive steps at once, on the last ring entry of each group of FG -- one burst of FG steps
             // per stream instead of FG separate requests (tools/streambench.hip: 3.8 -> 4.7 TB/s for FG = 4)
@@ -312,14 +326,20 @@ int launch_ff(const isls_ff_args &a, hipStream_t s)
     if (segmented && (a.seg.nseg > 16 || !a.seg.Psi || !a.seg.v || (int64_t)a.seg.nseg * a.seg.seg_len < a.N - 1 ||
                       (int64_t)(a.seg.nseg - 1) * a.seg.seg_len >= a.N - 1))
         return ISLS_ERR_ARG;
+    // weights that do not depend on the time step (or are absent) are loaded once per lane instead of once per step
+    const bool rowc = (!a.Qr.p || a.Qr.st == 0) && (!a.Rr.p || a.Rr.st == 0);
 #define CALL(NX_, NU_)                                                                                 \
     {                                                                                                  \
         p.tpw = pick_tpw(a.B, kWave / (NX_ + NU_), "ISLS_FF_TPW");                                     \
         const int grid = (a.B + p.tpw - 1) / p.tpw;                                                    \
-        if (segmented)                                                                                 \
-            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfSegDepth, kFfSegOcc, kFfSegGroup>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
+        if (segmented && rowc)                                                                         \
+            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfSegDepth, kFfSegOcc, kFfSegGroup, true>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
+        else if (segmented)                                                                            \
+            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfSegDepth, kFfSegOcc, kFfSegGroup, false>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
+        else if (rowc)                                                                                 \
+            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth, 1, kFfGroup, true>), dim3(grid), dim3(64), 0, s, p);  \
         else                                                                                           \
-            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth, 1, kFfGroup>), dim3(grid), dim3(64), 0, s, p);  \
+            hipLaunchKernelGGL((riccati_ff_kernel<T, NX_, NU_, kFfDepth, 1, kFfGroup, false>), dim3(grid), dim3(64), 0, s, p); \
     }
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
