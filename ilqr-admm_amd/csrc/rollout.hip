@@ -163,8 +163,12 @@ struct RoLayout {
     __host__ __device__ static constexpr int slot_elems(int L, int GL, int nseg) { return 2 * RECP + 2 * GL + MDL + (L + 1) * nseg * NX + 1; }
 };
 
+// register budget: two waves per SIMD where a batch of 4096 launches more waves than SIMDs (slots of >= 16 lanes), the whole
+// file for the 8-lane slots (8 trajectories per wave) and for the 9-state models in 16-lane slots (4 per wave)
+template <int NX, int GLMIN> constexpr int rollout_occupancy() { return (GLMIN >= 32 || (GLMIN >= 16 && NX < 9)) ? 2 : 1; }
+
 template <typename T, int NX, int NU, int MODEL, int GLMIN>
-__global__ __launch_bounds__(64, 2) void rollout_kernel(RoP<T> p)
+__global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_kernel(RoP<T> p)
 {
     using LY = RoLayout<NX, NU>;
     constexpr int D = kRolloutDepth;
