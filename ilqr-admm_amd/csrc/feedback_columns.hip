@@ -1,0 +1,236 @@
+// feedback_columns.hip -- x-step roll-out and z/dual bookkeeping of the feedback columns [d, phi] of
+// iSLS.isls_admm (isls/isls.py:503-712) in DP form; see isls_columns_args in include/isls_hip.h.
+//
+// Work shape: B problems x C = 1 + dim columns (C <= 4), N dependent steps of an n x (n + m) mat-vec each.  The
+// columns of one problem share A_t, B_t, K_t, so they sit in neighbouring lanes (column index fastest) and the
+// per-step operands are fetched once per cache line for the whole group.  The pass runs once per ADMM iteration
+// next to C feed-forward passes and one line-search rollout and is a small fraction of them.
+#include "isls_common.hpp"
+
+namespace isls {
+
+template <typename T>
+struct ColP {
+    int B, N, C;
+    View<T> A, Bm, Cuu, c0u, Rr;
+    const T *K, *k, *zu, *lu;
+    T *dx, *du;
+    const int32_t *active;
+};
+
+template <typename T, int NX, int NU>
+__global__ __launch_bounds__(64) void columns_rollout_kernel(ColP<T> p)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    const int b = gid / p.C, c = gid - b * p.C;
+    if (b >= p.B) return;
+    if (p.active && !p.active[b]) return;
+    const int N = p.N;
+    const int64_t col = (int64_t)c * p.B + b;
+    T *dx = p.dx + col * N * NX, *du = p.du + col * N * NU;
+    const T *kc = p.k + col * N * NU;
+    const T *Kb = p.K + (int64_t)b * N * NU * NX;
+    T x[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = (c >= 1 && i == c - 1) ? T(1) : T(0);
+    for (int t = 0; t < N - 1; ++t) {
+        const T *Kt = Kb + (int64_t)t * NU * NX, *At = p.A.at(b, t), *Bt = p.Bm.at(b, t);
+        T u[NU], xn[NX];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+            T acc = kc[t * NU + r];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) acc += Kt[r * NX + j] * x[j];
+            u[r] = acc;
+            du[t * NU + r] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[t * NX + i] = x[i];
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) acc += At[a * NX + j] * x[j];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) acc += Bt[a * NU + r] * u[r];
+            xn[a] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[(N - 1) * NX + i] = x[i];
+    // last control: minimiser of its own cost term  (R + Rr) du = R ud + Rr u_reg  (isls.py:560-571, last block row)
+    T g[NU], H[NU][NU], U[NU][NU], rd[NU], y[NU];
+    const T *Cl = p.Cuu.at(b, N - 1);
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+        g[r] = c == 0 ? -p.c0u.at(b, N - 1)[r] : T(0);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) H[r][j] = Cl[r * NU + j];
+    }
+    if (p.Rr.p) {
+        const T *Rl = p.Rr.at(b, N - 1);
+        const T *z = p.zu + col * N * NU + (N - 1) * NU, *l = p.lu + col * N * NU + (N - 1) * NU;
+#pragma unroll
+        for (int r = 0; r < NU; ++r)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) g[r] += T(2) * Rl[r * NU + j] * (z[j] - l[j]);
+    }
+    chol_upper<NU>(H, U, rd);
+    chol_solve<NU>(U, rd, g, y);
+#pragma unroll
+    for (int r = 0; r < NU; ++r) du[(N - 1) * NU + r] = y[r];
+}
+
+template <typename T>
+int launch_columns_rollout(const isls_columns_args &a, hipStream_t s)
+{
+    if (a.B < 0 || a.N < 2 || a.C < 1 || a.C > 1 + a.n || a.C > ISLS_MAX_ROW_DIM) return ISLS_ERR_ARG;
+    if (!a.A.p || !a.Bm.p || !a.Cuu.p || !a.c0u.p || !a.K || !a.k || !a.dx || !a.du) return ISLS_ERR_ARG;
+    if (a.Rr.p && (!a.zu || !a.lu)) return ISLS_ERR_ARG;
+    if (a.B == 0) return ISLS_OK;
+    ColP<T> p;
+    p.B = a.B; p.N = a.N; p.C = a.C;
+    p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.Cuu = View<T>(a.Cuu); p.c0u = View<T>(a.c0u); p.Rr = View<T>(a.Rr);
+    p.K = (const T *)a.K; p.k = (const T *)a.k; p.zu = (const T *)a.zu; p.lu = (const T *)a.lu;
+    p.dx = (T *)a.dx; p.du = (T *)a.du; p.active = a.active;
+    const int blocks = (a.B * a.C + 63) / 64;
+#define CALL(NX_, NU_) hipLaunchKernelGGL((columns_rollout_kernel<T, NX_, NU_>), dim3(blocks), dim3(64), 0, s, p)
+    ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
+#undef CALL
+    return check_launch();
+}
+template int launch_columns_rollout<double>(const isls_columns_args &, hipStream_t);
+template int launch_columns_rollout<float>(const isls_columns_args &, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------------
+// z / dual step around the row projection (isls.py:626-665): one workgroup per problem, one thread per (step, column).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kColMaxD = 9;
+constexpr int kColThreads = 256;
+
+template <typename T>
+struct ColAdmmP {
+    int B, N, C, phase;
+    T relax, tol_abs, tol_rel;
+    int d[2];
+    const T *x[2];
+    T *z[2], *l[2], *zprev[2], *work[2];
+    const T *nom[2];
+    View<T> W[2];
+    T *res, *res_prev;
+    int32_t *active, *iters;
+};
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T *sh)
+{
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    T tot = T(0);
+    for (int i = 0; i < kColThreads / 64; ++i) tot += sh[i];
+    return tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kColThreads) void columns_admm_kernel(ColAdmmP<T> p)
+{
+    __shared__ T sh[kColThreads / 64];
+    const int b = blockIdx.x;
+    if (p.active && !p.active[b]) return;                      // uniform over the workgroup
+    const int N = p.N, C = p.C;
+    T prim = T(0), dual = T(0);
+    for (int blk = 0; blk < 2; ++blk) {
+        const int d = p.d[blk];
+        if (d == 0) continue;
+        T accp = T(0), accd = T(0);
+        for (int it = threadIdx.x; it < N * C; it += kColThreads) {
+            const int t = it / C, c = it - t * C;
+            const int64_t e0 = (((int64_t)c * p.B + b) * N + t) * d;
+            const int64_t w0 = ((int64_t)b * N + t) * d;         // row (t, i) of problem b is w0 + i
+            const bool shift = c == 0 && p.nom[blk] != nullptr;
+            if (p.phase == 0) {
+                for (int i = 0; i < d; ++i) {
+                    const T zi = p.z[blk][e0 + i];
+                    T v = p.relax * p.x[blk][e0 + i] + (T(1) - p.relax) * zi + p.l[blk][e0 + i];
+                    if (shift) v += p.nom[blk][w0 + i];
+                    p.work[blk][(w0 + i) * C + c] = v;
+                    p.zprev[blk][e0 + i] = zi;
+                }
+            } else {
+                T r[kColMaxD], dz[kColMaxD];
+                for (int i = 0; i < d; ++i) {
+                    T zn = p.work[blk][(w0 + i) * C + c];
+                    if (shift) zn -= p.nom[blk][w0 + i];
+                    r[i] = p.x[blk][e0 + i] - zn;
+                    dz[i] = zn - p.zprev[blk][e0 + i];
+                    p.l[blk][e0 + i] += r[i];
+                    p.z[blk][e0 + i] = zn;
+                }
+                const T *W = p.W[blk].at(b, t);
+                for (int i = 0; i < d; ++i) {
+                    T wr = T(0), wz = T(0);
+                    for (int j = 0; j < d; ++j) {
+                        wr += W[i * d + j] * r[j];
+                        wz += W[i * d + j] * dz[j];
+                    }
+                    accp += wr * wr;
+                    accd += wz * wz;
+                }
+            }
+        }
+        if (p.phase == 1) {
+            prim += sqrt(block_sum(accp, sh));
+            dual += sqrt(block_sum(accd, sh));
+        }
+    }
+    if (p.phase == 1 && threadIdx.x == 0) {
+        const T pp = p.res_prev[2 * b], dp = p.res_prev[2 * b + 1];
+        p.res[2 * b] = prim;
+        p.res[2 * b + 1] = dual;
+        p.res_prev[2 * b] = prim;
+        p.res_prev[2 * b + 1] = dual;
+        if (p.iters) p.iters[b] += 1;
+        if (p.active) {
+            bool stop = prim < p.tol_abs && dual < p.tol_abs;
+            if (!stop) {
+                const T pc = fabs(pp - prim) / (pp + T(1e-30)), dc = fabs(dp - dual) / (dp + T(1e-30));
+                stop = pc < p.tol_rel && dc < p.tol_rel;
+            }
+            if (stop) p.active[b] = 0;
+        }
+    }
+}
+
+template <typename T>
+int launch_columns_admm(const isls_columns_admm_args &a, hipStream_t s)
+{
+    if (a.B < 0 || a.N < 1 || a.C < 1 || a.C > ISLS_MAX_ROW_DIM || (a.phase != 0 && a.phase != 1)) return ISLS_ERR_ARG;
+    if (a.n < 1 || a.n > kColMaxD || a.m < 1 || a.m > kColMaxD) return ISLS_ERR_UNSUPPORTED;
+    if (!a.xx && !a.xu) return ISLS_ERR_ARG;
+    if (a.xx && (!a.zx || !a.lx || !a.zx_prev || !a.x_work || !a.Qr.p)) return ISLS_ERR_ARG;
+    if (a.xu && (!a.zu || !a.lu || !a.zu_prev || !a.u_work || !a.Rr.p)) return ISLS_ERR_ARG;
+    if (!a.res || !a.res_prev) return ISLS_ERR_ARG;
+    if (a.B == 0) return ISLS_OK;
+    ColAdmmP<T> p;
+    p.B = a.B; p.N = a.N; p.C = a.C; p.phase = a.phase;
+    p.relax = (T)a.relax; p.tol_abs = (T)a.tol_abs; p.tol_rel = (T)a.tol_rel;
+    p.d[0] = a.xx ? a.n : 0; p.d[1] = a.xu ? a.m : 0;
+    p.x[0] = (const T *)a.xx; p.x[1] = (const T *)a.xu;
+    p.z[0] = (T *)a.zx; p.z[1] = (T *)a.zu; p.l[0] = (T *)a.lx; p.l[1] = (T *)a.lu;
+    p.zprev[0] = (T *)a.zx_prev; p.zprev[1] = (T *)a.zu_prev;
+    p.work[0] = (T *)a.x_work; p.work[1] = (T *)a.u_work;
+    p.nom[0] = (const T *)a.x_nom; p.nom[1] = (const T *)a.u_nom;
+    p.W[0] = View<T>(a.Qr); p.W[1] = View<T>(a.Rr);
+    p.res = (T *)a.res; p.res_prev = (T *)a.res_prev; p.active = a.active; p.iters = a.iters;
+    hipLaunchKernelGGL((columns_admm_kernel<T>), dim3(a.B), dim3(kColThreads), 0, s, p);
+    return check_launch();
+}
+template int launch_columns_admm<double>(const isls_columns_admm_args &, hipStream_t);
+template int launch_columns_admm<float>(const isls_columns_admm_args &, hipStream_t);
+
+}  // namespace isls

@@ -142,6 +142,23 @@ class SlsAdmmArgs(C.Structure):
                 ("x_u", C.c_void_p), ("z", C.c_void_p), ("lmb", C.c_void_p), ("logs", C.c_void_p), ("iters", C.c_void_p)]
 
 
+class ColumnsArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("C", C.c_int32), ("_pad", C.c_int32),
+                ("A", View), ("Bm", View), ("Cuu", View), ("c0u", View), ("Rr", View),
+                ("K", C.c_void_p), ("k", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
+                ("dx", C.c_void_p), ("du", C.c_void_p), ("active", C.c_void_p)]
+
+
+class ColumnsAdmmArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("C", C.c_int32), ("phase", C.c_int32),
+                ("relax", C.c_double), ("tol_abs", C.c_double), ("tol_rel", C.c_double),
+                ("xx", C.c_void_p), ("xu", C.c_void_p),
+                ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
+                ("zx_prev", C.c_void_p), ("zu_prev", C.c_void_p), ("x_nom", C.c_void_p), ("u_nom", C.c_void_p),
+                ("x_work", C.c_void_p), ("u_work", C.c_void_p), ("Qr", View), ("Rr", View),
+                ("res", C.c_void_p), ("res_prev", C.c_void_p), ("active", C.c_void_p), ("iters", C.c_void_p)]
+
+
 class OuterArgs(C.Structure):
     _fields_ = [("gain", GainArgs), ("ff", FfArgs), ("ro", RolloutArgs), ("admm", AdmmArgs),
                 ("J", C.c_int32), ("skip_gain", C.c_int32), ("log", C.c_void_p), ("outer_active", C.c_void_p)]
@@ -149,7 +166,7 @@ class OuterArgs(C.Structure):
 
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
-            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "expand_quadratic", "linearize",
+            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
            ["isls_ff_segments", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_pause",
             "isls_timing_read_ms"]
@@ -463,6 +480,40 @@ class Kernels:
         a.logs, a.iters = _ptr(_dense(logs, (P, int(max_iter), 2), "logs")), _ptr(iters)
         a._keep = pa
         return self._call("sls_admm", _sfx(r_side), a, stream)
+
+    def columns_rollout(self, A, Bm, Cuu, c0u, K, k, dx, du, Rr=None, zu=None, lu=None, active=None, stream=None):
+        """isls_columns_rollout: k, dx, du column-major [C,B,N,.]; A, Bm, Cuu, c0u, Rr broadcastable views."""
+        Cc, B, N, n = dx.shape
+        m = du.shape[3]
+        a = ColumnsArgs(B=B, N=N, n=n, m=m, C=Cc)
+        a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
+        a.Cuu, a.c0u = make_view(Cuu, B, N, (m, m), "Cuu"), make_view(c0u, B, N, (m,), "c0u")
+        a.Rr = make_view(Rr, B, N, (m, m), "Rr")
+        a.K, a.k = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(k, (Cc, B, N, m), "k"))
+        a.zu, a.lu = _ptr(_dense(zu, (Cc, B, N, m), "zu")), _ptr(_dense(lu, (Cc, B, N, m), "lu"))
+        a.dx, a.du = _ptr(_dense(dx, (Cc, B, N, n), "dx")), _ptr(_dense(du, (Cc, B, N, m), "du"))
+        a.active = _ptr(active)
+        return self._call("columns_rollout", _sfx(dx), a, stream)
+
+    def columns_admm(self, phase, dims, res, res_prev, x=None, u=None, relax=1.0, tol_abs=0.0, tol_rel=1e-3, active=None,
+                     iters=None, stream=None):
+        """isls_columns_admm; dims = (B, N, n, m, C); x / u: dict(xx, z, l, z_prev, work, W, nom=None) or None."""
+        B, N, n, m, Cc = dims
+        a = ColumnsAdmmArgs(B=B, N=N, n=n, m=m, C=Cc, phase=int(phase), relax=float(relax), tol_abs=float(tol_abs),
+                            tol_rel=float(tol_rel))
+        for blk, d, names in ((x, n, ("xx", "zx", "lx", "zx_prev", "x_nom", "x_work", "Qr")),
+                              (u, m, ("xu", "zu", "lu", "zu_prev", "u_nom", "u_work", "Rr"))):
+            if blk is None:
+                continue
+            for key, name in zip(("xx", "z", "l", "z_prev"), names[:4]):
+                setattr(a, name, _ptr(_dense(blk[key], (Cc, B, N, d), name)))
+            setattr(a, names[4], _ptr(_dense(blk.get("nom"), (B, N, d), names[4])))
+            setattr(a, names[5], _ptr(_dense(blk["work"], (B, N * d, Cc), names[5])))
+            setattr(a, names[6], make_view(blk["W"], B, N, (d, d), names[6]))
+        a.res, a.res_prev = _ptr(_dense(res, (B, 2), "res")), _ptr(_dense(res_prev, (B, 2), "res_prev"))
+        a.active, a.iters = _ptr(active), _ptr(iters)
+        sample = (x or u)["xx"]
+        return self._call("columns_admm", _sfx(sample), a, stream)
 
     def sls_closed_loop(self, A, Bm, K, k, x0, x_log, u_log, stream=None):
         M, N, n = x_log.shape

@@ -8,6 +8,7 @@ numerical step runs in the HIP kernels behind `engine.Engine`:
     rollout_DP        -> rollout_ls                          (isls/isls.py:310-334)
     iterate_once_dp   -> gain, ff, rollout_ls(NaN rule, acceptance test)   (isls/isls.py:336-374)
     ilqr_admm         -> DP form: ilqr_admm_outer + accept_step            (isls/isls.py:379-501, "TODO: add dp solution")
+    isls_admm         -> DP form: gain + C x ff + columns_rollout + rollout_ls + columns_admm (isls/isls.py:503-712)
 
 Differences from the reference, all deliberate and documented in DESIGN.md: `ilqr_admm` uses the DP (Riccati)
 solve instead of the dense batch-form least squares (identical iterates except the never-applied last control,
@@ -22,6 +23,7 @@ from .admm import ADMM
 from .base import ALPHAS, Base
 from .models import Model
 from .projections import Box, ConvexSets
+from .robust import isls_admm as _isls_admm
 
 
 class iSLS(Base):
@@ -374,8 +376,7 @@ class iSLS(Base):
             e.zu.copy_(e._t(z_u.reshape(B, N, m))), e.lu.copy_(e._t(l_u.reshape(B, N, m)))
         return res
 
-    def isls_admm(self, *a, **k):
-        raise NotImplementedError("isls_admm (iterative SLS-ADMM with feedback columns) is the first 'next' row (SURVEY 8f-1)")
+    isls_admm = _isls_admm                                      # isls/isls.py:503-712, DP form (robust.py)
 
     def rollout_batch(self, *a, **k):
         raise NotImplementedError("batch-form iLQR is out of scope (SURVEY 2, row 10); use the DP form")

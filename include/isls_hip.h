@@ -349,6 +349,68 @@ int isls_sls_closed_loop_f32(int32_t M, int32_t N, int32_t n, int32_t m, const v
                              const void *k, const void *x0, void *x_log, void *u_log, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Feedback columns of iSLS.isls_admm (isls/isls.py:503-712) in DP form.
+ * The reference solves, per outer iteration, the dense normal equations
+ *   [d_u, phi_u] = (Su'Q Su + R + Su'Qr Su + Rr)^-1 (r_side + Su'Qr x_reg + Rr u_reg)      (isls.py:571,580-588)
+ *   [d_x, phi_x] = Su [d_u, phi_u] + [0, Sx]                                                (isls.py:589-590)
+ * for the C = 1 + dim columns at once.  Column c is the minimiser of one time-varying LQ problem about the
+ * nominal: column 0 with the cost gradients of the nominal and delta x_0 = 0, column j >= 1 with no cost
+ * gradient and delta x_0 = e_j (first `dim` states), each with its own ADMM target (z - lmb)[c].  All columns
+ * share the gains K_t of ONE Riccati gain pass (isls_riccati_gain_*); their feed-forward terms k[c] come from
+ * C feed-forward passes (isls_riccati_ff_* with xhat = uhat = NULL and, for c >= 1, zero c0x / c0u), and this
+ * entry point rolls them through the linearised dynamics:
+ *   dx_0 = e_c ; du_t = K_t dx_t + k[c]_t ; dx_{t+1} = A_t dx_t + B_t du_t           (t < N-1)
+ *   du_{N-1} = -Cuu_{N-1}^-1 ( [c == 0] c0u_{N-1} - 2 Rr_{N-1} (zu - lu)[c]_{N-1} )
+ * The last control never acts on the state (SURVEY 8a quirk i): the dense form gives it the minimiser of its
+ * own cost term, reproduced by the second line.  Arrays with a leading C are column-major: [C,B,N,.].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_columns_args {
+    int32_t B, N, n, m;
+    int32_t C;              /* 1 + dim                                                            */
+    int32_t _pad;
+    isls_view A, Bm;        /* [.,.,n,n], [.,.,n,m]                                               */
+    isls_view Cuu;          /* [.,.,m,m] control Hessian of the gain pass (2 R + 2 Rr)            */
+    isls_view c0u;          /* [.,.,m]   control gradient at the nominal (2 R uhat)               */
+    isls_view Rr;           /* [.,.,m,m] nullable (project_u False)                               */
+    const void *K;          /* [B,N,m,n]                                                          */
+    const void *k;          /* [C,B,N,m]                                                          */
+    const void *zu, *lu;    /* [C,B,N,m] nullable with Rr                                         */
+    void *dx, *du;          /* [C,B,N,n], [C,B,N,m] out                                           */
+    const int32_t *active;  /* [B] nullable                                                       */
+} isls_columns_args;
+
+int isls_columns_rollout_f64(const isls_columns_args *a, void *stream);
+int isls_columns_rollout_f32(const isls_columns_args *a, void *stream);
+
+/* z / dual step of isls_admm around the row projection (isls/isls.py:626-665), in two phases:
+ *   phase 0:  z_prev <- z ;  work[b, t*d+i, c] <- relax x + (1-relax) z + lmb  (+ nom[b,t,i] for c == 0)
+ *             ... project the rows of `work` (isls_project_rows_* on [B, N*d, C], or the caller's function) ...
+ *   phase 1:  z <- work (- nom for c == 0) ; r = x - z ; lmb += r
+ *             prim = |Qr r_x|_F + |Rr r_u|_F , dual = |Qr (z_x - z_prev_x)|_F + |Rr (z_u - z_prev_u)|_F
+ *             stop if prim < tol_abs and dual < tol_abs, else if both relative changes (+1e-30) < tol_rel (1e-3)
+ * `nom` is the nominal the notebooks add to the d column before projecting and remove afterwards
+ * (notebooks/3DoF robot/State bounds and robust control bounds.ipynb cell 25); NULL when the caller's projection
+ * does that itself.  A block with x == NULL is absent (project_x / project_u False).  res / res_prev / active /
+ * iters as in isls_admm_args. */
+typedef struct isls_columns_admm_args {
+    int32_t B, N, n, m;
+    int32_t C, phase;
+    double relax, tol_abs, tol_rel;
+    const void *xx, *xu;          /* [C,B,N,n], [C,B,N,m] x-step (nullable per block)             */
+    void *zx, *lx, *zu, *lu;      /* [C,B,N,.]                                                    */
+    void *zx_prev, *zu_prev;      /* [C,B,N,.] scratch between the phases                         */
+    const void *x_nom, *u_nom;    /* [B,N,n], [B,N,m] nullable                                    */
+    void *x_work, *u_work;        /* [B,N*n,C], [B,N*m,C] projection argument / result            */
+    isls_view Qr, Rr;             /* residual weights, [.,.,n,n] / [.,.,m,m]                      */
+    void *res, *res_prev;         /* [B,2]                                                        */
+    int32_t *active;              /* [B] nullable                                                 */
+    int32_t *iters;               /* [B] nullable                                                 */
+} isls_columns_admm_args;
+
+int isls_columns_admm_f64(const isls_columns_admm_args *a, void *stream);
+int isls_columns_admm_f32(const isls_columns_admm_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Quadratic via-point cost expansion about the nominal (the `Cts is None` branch of
  * backward_pass_DP, isls/isls.py:263-271, written out as arrays, plus the ADMM regulariser):
  *   Cxx[b,t] = 2 Q_t (+ 2 Qr_t) ; Cuu[b,t] = 2 u_std I (+ 2 Rr_t)

@@ -793,8 +793,67 @@ def gen_tassa():
     save("g8_tassa.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G9: iSLS.isls_admm (isls/isls.py:503-712, shimmed) on the 3R arm with the chance constraint on the controls of
+# notebooks/3DoF robot/State bounds and robust control bounds.ipynb cells 24-26
+# ---------------------------------------------------------------------------------------------
+def robust_control_rows(q_dim, upper, lower, var_x0, psi_inv):
+    """A_, b_ of the two unit-SOC images of the chance constraint on a row [u_nom + d_u, phi_u]."""
+    mu = np.zeros(1 + q_dim)
+    mu[0] = 1.0
+    root = np.diag(np.sqrt(np.concatenate([[0.0], np.full(q_dim, var_x0)])))
+    A_ = [np.concatenate([root, (-mu / psi_inv)[None]], axis=0), np.concatenate([root, (mu / psi_inv)[None]], axis=0)]
+    b_ = [np.append(np.zeros(1 + q_dim), upper / psi_inv), np.append(np.zeros(1 + q_dim), -lower / psi_inv)]
+    return A_, b_
+
+
+def gen_isls_admm():
+    import contextlib
+    import io
+    from scipy.stats import norm
+    out = {}
+    N, q_dim = 40, 3
+    cfg = P.config3(batch=2, N=N, seed=3)
+    cfg["u0"] = np.zeros_like(cfg["u0"])                       # notebook cell 26 starts from zero controls
+    upper, lower, var_x0, psi_inv = 6.0, -6.0, 0.1, float(norm.ppf(0.82))
+    A_, b_ = robust_control_rows(q_dim, upper, lower, var_x0, psi_inv)
+    out.update(upper=np.array(upper), lower=np.array(lower), var_x0=np.array(var_x0), psi_inv=np.array(psi_inv))
+    res = {k_: [] for k_ in ("du", "phi_u", "x_nom", "u_nom", "cost_log", "n_outer", "unc_du", "unc_phi_u", "unc_cost_log",
+                             "proj_in", "proj_out", "n_proj")}
+    for b in range(2):
+        calls_in, calls_out = [], []
+
+        def project_u(u, u_nom):
+            y = u.copy()
+            y[:, 0] += u_nom.flatten()
+            calls_in.append(y.copy())
+            y = refproj.project_set_convex(y, A_, b_, projections=[refproj.project_soc_unit] * 2, rho=1e1, max_iter=100,
+                                           threshold=1e-4, verbose=0)
+            calls_out.append(y.copy())
+            y[:, 0] -= u_nom.flatten()
+            return y
+        # unconstrained call (cell 23): feedback columns of the plain iLQR problem
+        obj, get_AB = make_ref_isls(cfg, b)
+        with contextlib.redirect_stdout(io.StringIO()):
+            du, phi_u = obj.isls_admm(q_dim, get_AB, max_line_search=10, k_max=3, max_admm_iter=1, threshold=1e-4, log=True)
+        res["unc_du"].append(du), res["unc_phi_u"].append(phi_u)
+        res["unc_cost_log"].append(np.array(obj.cost_log, dtype=float)[:4])
+        # robust control bounds (cell 26), 3 outer iterations x <= 10 ADMM iterations
+        obj, get_AB = make_ref_isls(cfg, b)
+        with contextlib.redirect_stdout(io.StringIO()):
+            du, phi_u = obj.isls_admm(q_dim, get_AB, max_line_search=30, k_max=3, project_u=project_u, rho_u=1.0,
+                                      max_admm_iter=10, threshold=1e-4, verbose=0, log=True)
+        print("isls_admm problem", b, "cost log", obj.cost_log, "projection calls", len(calls_in))
+        res["du"].append(du), res["phi_u"].append(phi_u), res["x_nom"].append(obj.x_nom.copy()), res["u_nom"].append(obj.u_nom.copy())
+        res["cost_log"].append(np.array(obj.cost_log, dtype=float)[:4]), res["n_outer"].append(len(obj.cost_log) - 1)
+        # arguments and results of the projection during the first outer iteration (one call per ADMM iteration)
+        res["proj_in"].append(np.stack(calls_in[:10])), res["proj_out"].append(np.stack(calls_out[:10])), res["n_proj"].append(len(calls_in))
+    out.update(x0=cfg["x0"], **{k_: np.stack(v) for k_, v in res.items()})
+    save("g9_isls_admm.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa"]
+    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm"]
     for w in which:
         {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections, "sls": gen_sls,
-         "tassa": gen_tassa}[w]()
+         "tassa": gen_tassa, "isls_admm": gen_isls_admm}[w]()

@@ -242,7 +242,7 @@ def test_unbuilt_paths_fail_loudly():
     with pytest.raises(NotImplementedError):
         s.forward_model = lambda x, u: x
     with pytest.raises(NotImplementedError):
-        s.isls_admm(3, None)
+        s.rollout_batch(None, None)
     sl = isls.SLS(2, 1, 20)
     with pytest.raises(NotImplementedError):
         sl.ADMM_SLS()
