@@ -162,6 +162,14 @@ ISLS_API int isls_sls_closed_loop_f32(int32_t M, int32_t N, int32_t n, int32_t m
 {
     return launch_sls_closed_loop<float>(M, N, n, m, A, B, K, k, x0, x_log, u_log, (hipStream_t)stream);
 }
+ISLS_API int isls_dense_closed_loop_f64(const isls_dense_loop_args *a, void *stream)
+{
+    return a ? launch_dense_closed_loop<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_dense_closed_loop_f32(const isls_dense_loop_args *a, void *stream)
+{
+    return a ? launch_dense_closed_loop<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
 ISLS_API int isls_columns_rollout_f64(const isls_columns_args *a, void *stream)
 {
     return a ? launch_columns_rollout<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;

@@ -178,6 +178,7 @@ template <typename T> int launch_sls_admm(const isls_sls_admm_args &a, hipStream
 template <typename T>
 int launch_sls_closed_loop(int M, int N, int n, int m, const void *A, const void *B, const void *K, const void *k,
                            const void *x0, void *x_log, void *u_log, hipStream_t s);
+template <typename T> int launch_dense_closed_loop(const isls_dense_loop_args &a, hipStream_t s);
 template <typename T> int launch_columns_rollout(const isls_columns_args &a, hipStream_t s);
 template <typename T> int launch_columns_admm(const isls_columns_admm_args &a, hipStream_t s);
 template <typename T> int launch_expand(const isls_expand_args &a, hipStream_t s);

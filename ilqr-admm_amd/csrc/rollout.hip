@@ -619,6 +619,79 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_ar
 template int launch_rollout<double>(const isls_rollout_args &, hipStream_t, const isls_admm_args *, bool *);
 template int launch_rollout<float>(const isls_rollout_args &, hipStream_t, const isls_admm_args *, bool *);
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Monte-Carlo closed loop of a dense causal controller about a nominal (iSLSBase.get_trajectory_sls,
+// isls/isls_base.py:28-42): one thread per initial state, the state history is the thread's own x_log row.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct DenseLoopP {
+    int M, N;
+    const T *par, *K, *k, *xhat, *uhat, *x0;
+    T *x_log, *u_log;
+};
+
+template <typename T, int NX, int NU, int MODEL>
+__global__ __launch_bounds__(64) void dense_closed_loop_kernel(DenseLoopP<T> p)
+{
+    extern __shared__ __align__(16) unsigned char dl_smem[];
+    Model<T, NX, NU, MODEL> mdl;
+    mdl.load(p.par, reinterpret_cast<T *>(dl_smem), threadIdx.x, 64);
+    __syncthreads();
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= p.M) return;
+    const int N = p.N;
+    T *xs = p.x_log + (int64_t)s * N * NX, *us = p.u_log + (int64_t)s * N * NU;
+    T x[NX], u[NU], xn[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) x[j] = p.x0[(int64_t)s * NX + j];
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xs[i * NX + j] = x[j];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+            const T *Kr = p.K + (int64_t)(i * NU + r) * N * NX;
+            T acc = T(0);
+            for (int j = 0; j < (i + 1) * NX; ++j) acc += (xs[j] - (p.xhat ? p.xhat[j] : T(0))) * Kr[j];
+            u[r] = (acc + p.k[i * NU + r]) + (p.uhat ? p.uhat[i * NU + r] : T(0));
+            us[i * NU + r] = u[r];
+        }
+        mdl.step(x, u, xn);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) x[j] = xn[j];
+    }
+}
+
+template <typename T>
+int launch_dense_closed_loop(const isls_dense_loop_args &a, hipStream_t s)
+{
+    if (a.M < 0 || a.N < 1 || !a.model_par || !a.K || !a.k || !a.x0 || !a.x_log || !a.u_log) return ISLS_ERR_ARG;
+    if (a.M == 0) return ISLS_OK;
+    DenseLoopP<T> p;
+    p.M = a.M; p.N = a.N;
+    p.par = (const T *)a.model_par; p.K = (const T *)a.K; p.k = (const T *)a.k;
+    p.xhat = (const T *)a.xhat; p.uhat = (const T *)a.uhat; p.x0 = (const T *)a.x0;
+    p.x_log = (T *)a.x_log; p.u_log = (T *)a.u_log;
+    const int grid = (a.M + 63) / 64;
+#define LAUNCH(NX_, NU_, MODEL_)                                                                                          \
+    hipLaunchKernelGGL((dense_closed_loop_kernel<T, NX_, NU_, MODEL_>), dim3(grid), dim3(64),                              \
+                       sizeof(T) * (Model<T, NX_, NU_, MODEL_>::LDS_WORDS + 1), s, p)
+    if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_LTI) LAUNCH(4, 2, ISLS_MODEL_LTI);
+    else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_CAR) LAUNCH(4, 2, ISLS_MODEL_CAR);
+    else if (a.n == 9 && a.m == 3 && a.model == ISLS_MODEL_LTI) LAUNCH(9, 3, ISLS_MODEL_LTI);
+    else if (a.n == 9 && a.m == 3 && a.model == ISLS_MODEL_ARM3R) LAUNCH(9, 3, ISLS_MODEL_ARM3R);
+    else if (a.n == 6 && a.m == 3 && a.model == ISLS_MODEL_LTI) LAUNCH(6, 3, ISLS_MODEL_LTI);
+    else if (a.n == 2 && a.m == 1 && a.model == ISLS_MODEL_LTI) LAUNCH(2, 1, ISLS_MODEL_LTI);
+    else if (a.n == 6 && a.m == 3 && a.model == ISLS_MODEL_DI) LAUNCH(6, 3, ISLS_MODEL_DI);
+    else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_DI) LAUNCH(4, 2, ISLS_MODEL_DI);
+    else if (a.n == 2 && a.m == 1 && a.model == ISLS_MODEL_DI) LAUNCH(2, 1, ISLS_MODEL_DI);
+    else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_TASSA) LAUNCH(4, 2, ISLS_MODEL_TASSA);
+    else return ISLS_ERR_UNSUPPORTED;
+#undef LAUNCH
+    return check_launch();
+}
+template int launch_dense_closed_loop<double>(const isls_dense_loop_args &, hipStream_t);
+template int launch_dense_closed_loop<float>(const isls_dense_loop_args &, hipStream_t);
+
 // The ADMM update can ride on the winner replay when it is the plain element-wise form (no set projections), works
 // on the arrays this rollout writes, shares its active mask and no acceptance test can keep the old nominal.
 bool rollout_can_fuse_admm(const isls_rollout_args &r, const isls_admm_args &a)

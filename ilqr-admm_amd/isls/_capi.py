@@ -149,6 +149,12 @@ class ColumnsArgs(C.Structure):
                 ("dx", C.c_void_p), ("du", C.c_void_p), ("active", C.c_void_p)]
 
 
+class DenseLoopArgs(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("model", C.c_int32), ("_pad", C.c_int32),
+                ("model_par", C.c_void_p), ("K", C.c_void_p), ("k", C.c_void_p), ("xhat", C.c_void_p), ("uhat", C.c_void_p),
+                ("x0", C.c_void_p), ("x_log", C.c_void_p), ("u_log", C.c_void_p)]
+
+
 class ColumnsAdmmArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("C", C.c_int32), ("phase", C.c_int32),
                 ("relax", C.c_double), ("tol_abs", C.c_double), ("tol_rel", C.c_double),
@@ -166,7 +172,7 @@ class OuterArgs(C.Structure):
 
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
-            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "expand_quadratic", "linearize",
+            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
            ["isls_ff_segments", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_pause",
             "isls_timing_read_ms"]
@@ -480,6 +486,16 @@ class Kernels:
         a.logs, a.iters = _ptr(_dense(logs, (P, int(max_iter), 2), "logs")), _ptr(iters)
         a._keep = pa
         return self._call("sls_admm", _sfx(r_side), a, stream)
+
+    def dense_closed_loop(self, model, model_par, K, k, x0, x_log, u_log, xhat=None, uhat=None, stream=None):
+        """isls_dense_closed_loop: K [N m, N n], k [N m], x0 [M,n], nominal xhat [N,n] / uhat [N,m] of one problem."""
+        M, N, n = x_log.shape
+        m = u_log.shape[2]
+        a = DenseLoopArgs(M=M, N=N, n=n, m=m, model=int(model))
+        a.model_par, a.K, a.k = _ptr(model_par), _ptr(_dense(K, (N * m, N * n), "K")), _ptr(_dense(k, (N * m,), "k"))
+        a.xhat, a.uhat = _ptr(_dense(xhat, (N, n), "xhat")), _ptr(_dense(uhat, (N, m), "uhat"))
+        a.x0, a.x_log, a.u_log = _ptr(_dense(x0, (M, n), "x0")), _ptr(x_log), _ptr(_dense(u_log, (M, N, m), "u_log"))
+        return self._call("dense_closed_loop", _sfx(x_log), a, stream)
 
     def columns_rollout(self, A, Bm, Cuu, c0u, K, k, dx, du, Rr=None, zu=None, lu=None, active=None, stream=None):
         """isls_columns_rollout: k, dx, du column-major [C,B,N,.]; A, Bm, Cuu, c0u, Rr broadcastable views."""

@@ -378,6 +378,40 @@ class iSLS(Base):
 
     isls_admm = _isls_admm                                      # isls/isls.py:503-712, DP form (robust.py)
 
+    def controller(self, PHI_U, du):
+        """K = Phi_u Phi_x^-1, k = (I - K Su) du with the transfer matrices of the last linearisation (notebook-era
+        `iSLS.controller`, isls/sls.py:235-242 on `Base.AB`'s Sw / Su): dense host set-up per problem, as in the reference.
+        PHI_U [N m, N n] and du [N m] (leading batch axis when batched)."""
+        from . import sls_dense as dense
+        A, Bm = self.engine.A.cpu().numpy().astype(np.float64), self.engine.Bm.cpu().numpy().astype(np.float64)
+        PHI_U, du = np.asarray(PHI_U, dtype=np.float64), np.asarray(du, dtype=np.float64)
+        if self.batch == 1 and PHI_U.ndim == 2:
+            PHI_U, du = PHI_U[None], du[None]
+        Ks, ks = zip(*(dense.controller(*dense.transfer_matrices_ltv(np.broadcast_to(A[b], (self.N,) + A.shape[-2:]),
+                                                                   np.broadcast_to(Bm[b], (self.N,) + Bm.shape[-2:])), PHI_U[b], du[b])
+                       for b in range(self.batch)))
+        return (Ks[0], ks[0]) if self.batch == 1 else (np.stack(Ks), np.stack(ks))
+
+    def get_trajectory_sls(self, x0, K, k, noise_scale=0, problem=0):
+        """Monte-Carlo closed loop of the dense controller about the nominal of problem `problem` through the forward model
+        (isls/isls_base.py:28-42): x0 [M, n] -> (x_log [M,N,n], u_log [M,N,m]); one device thread per initial state."""
+        if noise_scale:
+            raise NotImplementedError("process noise is drawn on the host in the reference; not built")
+        e = self.engine
+        x0 = np.asarray(x0, dtype=np.float64)
+        single = x0.ndim == 1
+        x0 = np.atleast_2d(x0)
+        M = x0.shape[0]
+        dev = lambda a: e._t(np.ascontiguousarray(a))                           # noqa: E731
+        par = e.model_par if e.model_par.ndim == 1 else e.model_par[problem].contiguous()
+        x_log = torch.zeros(M, self.N, self.x_dim, dtype=e.dtype, device=e.device)
+        u_log = torch.zeros(M, self.N, self.u_dim, dtype=e.dtype, device=e.device)
+        e.kern.dense_closed_loop(e.model, par, dev(np.asarray(K)), dev(np.asarray(k)), dev(x0), x_log, u_log,
+                                 xhat=e.xhat[problem].contiguous(), uhat=e.uhat[problem].contiguous(),
+                                 stream=torch.cuda.current_stream().cuda_stream)
+        x, u = x_log.cpu().numpy().astype(np.float64), u_log.cpu().numpy().astype(np.float64)
+        return (x[0], u[0]) if single else (x, u)
+
     def rollout_batch(self, *a, **k):
         raise NotImplementedError("batch-form iLQR is out of scope (SURVEY 2, row 10); use the DP form")
 

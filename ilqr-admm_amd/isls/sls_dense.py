@@ -24,6 +24,21 @@ def transfer_matrices(A, B, N):
     return Sw, Su
 
 
+def transfer_matrices_ltv(A, B):
+    """Sw, Su of a time-varying linearisation A [N,n,n], B [N,n,m] (the `AB` setter, isls/base.py:98-119): block (i, j) of
+    Sw is A_{i-1} ... A_j, block (i, j) of Su is A_{i-1} ... A_{j+1} B_j, built row block by row block."""
+    N, n, m = A.shape[0], A.shape[1], B.shape[2]
+    Sw, Su = np.zeros((N * n, N * n)), np.zeros((N * n, N * m))
+    Sw[:n, :n] = np.eye(n)
+    for i in range(1, N):
+        r, pr = slice(i * n, (i + 1) * n), slice((i - 1) * n, i * n)
+        Sw[r, :i * n] = A[i - 1] @ Sw[pr, :i * n]
+        Sw[r, r] = np.eye(n)
+        Su[r, :i * m] = A[i - 1] @ Su[pr, :i * m]
+        Su[r, (i - 1) * m:i * m] = B[i - 1]
+    return Sw, Su
+
+
 def dense_cost(zs, Qs, seq, u_std, N, n, m):
     """Q [N n, N n] block diagonal, R [N m, N m] = u_std I, stacked targets xd [..., N n] (isls/base.py:81-89)."""
     Q = np.zeros((N * n, N * n))

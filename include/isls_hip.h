@@ -382,6 +382,24 @@ typedef struct isls_columns_args {
 int isls_columns_rollout_f64(const isls_columns_args *a, void *stream);
 int isls_columns_rollout_f32(const isls_columns_args *a, void *stream);
 
+/* Monte-Carlo closed loop of a dense causal controller about a nominal through a built-in forward model
+ * (iSLSBase.get_trajectory_sls, isls/isls_base.py:28-42, noise_scale = 0), M initial states:
+ *   dx_j = x_j - xhat_j (j <= i) ; u_i = (K [dx_0 .. dx_i, 0 ..] + k)_i + uhat_i ; x_{i+1} = f(x_i, u_i)
+ * K [N m, N n] (lower block triangular is not assumed, entries right of block i are not read), k [N m], the nominal
+ * xhat [N,n] / uhat [N,m] of ONE problem (NULL = 0: absolute form), x0 [M,n] -> x_log [M,N,n], u_log [M,N,m]. */
+typedef struct isls_dense_loop_args {
+    int32_t M, N, n, m;
+    int32_t model, _pad;
+    const void *model_par;
+    const void *K, *k;
+    const void *xhat, *uhat;
+    const void *x0;
+    void *x_log, *u_log;
+} isls_dense_loop_args;
+
+int isls_dense_closed_loop_f64(const isls_dense_loop_args *a, void *stream);
+int isls_dense_closed_loop_f32(const isls_dense_loop_args *a, void *stream);
+
 /* z / dual step of isls_admm around the row projection (isls/isls.py:626-665), in two phases:
  *   phase 0:  z_prev <- z ;  work[b, t*d+i, c] <- relax x + (1-relax) z + lmb  (+ nom[b,t,i] for c == 0)
  *             ... project the rows of `work` (isls_project_rows_* on [B, N*d, C], or the caller's function) ...

@@ -74,6 +74,7 @@ class DenseIslsAdmm:
         A, B = np.zeros((1, N, n, n)), np.zeros((1, N, n, m))
         self.kern.linearize(pa["model"], pa["model_par"], self.x_nom[None].copy(), self.u_nom[None].copy(), A, B)
         Sw, Su = transfer_matrices(A[0], B[0])
+        self.Sw, self.Su = Sw, Su                                               # what `controller` reads afterwards
         Sx = Sw[:, :dim]
         # quadratic-cost branch, isls.py:560-566
         xd, ud = self.xd - self.x_nom.reshape(-1), -self.u_nom.reshape(-1)
@@ -152,6 +153,14 @@ class DenseIslsAdmm:
                 break
         self.x_x, self.x_u = x_x, x_u
         return x_u[:, 0], x_u[:, 1:]
+
+
+def controller(Sw, Su, phi_u, du, n):
+    """K, k of SLS.controller (isls/sls.py:235-242) for feedback on the first columns only: PHI_U = [phi_u, 0]."""
+    PHI_U = np.zeros((Su.shape[1], Sw.shape[1]))
+    PHI_U[:, :phi_u.shape[1]] = phi_u
+    K = PHI_U @ np.linalg.inv(Sw + Su @ PHI_U)
+    return K, (np.eye(Su.shape[1]) - K @ Su) @ du
 
 
 def shifted_sets_projection(kern, cs):

@@ -20,6 +20,7 @@ extern "C" {
     int oracle_sls_closed_loop_##sfx(int32_t M, int32_t N, int32_t n, int32_t m, const void *A,       \
                                      const void *B, const void *K, const void *k, const void *x0,     \
                                      void *x_log, void *u_log);                                       \
+    int oracle_dense_closed_loop_##sfx(const isls_dense_loop_args *a);                                \
     int oracle_ilqr_admm_outer_##sfx(const isls_outer_args *a);
 ORACLE_DECL(f64)
 ORACLE_DECL(f32)

@@ -903,6 +903,37 @@ int FN(oracle_project_rows)(const isls_project_args *a)
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * Closed loop of a dense causal controller about a nominal (iSLSBase.get_trajectory_sls,
+ * isls/isls_base.py:28-42, noise_scale = 0): x_vec holds x_j - x_nom[j] for j <= i, zeros beyond;
+ * u_i = (x_vec @ K.T + k)[i] + u_nom[i] ; x_{i+1} = forward_model(x_i, u_i).
+ * ------------------------------------------------------------------------------------------- */
+int FN(oracle_dense_closed_loop)(const isls_dense_loop_args *a)
+{
+    const int M = a->M, N = a->N, n = a->n, m = a->m;
+    if (M < 0 || N < 1 || n < 1 || m < 1 || n > MAXN || m > MAXM) return ISLS_ERR_ARG;
+    const REAL *K = (const REAL *)a->K, *k = (const REAL *)a->k, *xh = (const REAL *)a->xhat, *uh = (const REAL *)a->uhat;
+#pragma omp parallel for schedule(static)
+    for (int s = 0; s < M; ++s) {
+        REAL *xs = (REAL *)a->x_log + (int64_t)s * N * n, *us = (REAL *)a->u_log + (int64_t)s * N * m;
+        REAL x[MAXN], xn[MAXN], u[MAXM];
+        for (int j = 0; j < n; ++j) x[j] = ((const REAL *)a->x0)[(int64_t)s * n + j];
+        for (int i = 0; i < N; ++i) {
+            for (int j = 0; j < n; ++j) xs[i * n + j] = x[j];
+            for (int r = 0; r < m; ++r) {
+                const REAL *Kr = K + (int64_t)(i * m + r) * N * n;
+                REAL acc = 0;
+                for (int j = 0; j < (i + 1) * n; ++j) acc += (xs[j] - (xh ? xh[j] : (REAL)0)) * Kr[j];
+                u[r] = (acc + k[i * m + r]) + (uh ? uh[i * m + r] : (REAL)0);
+                us[i * m + r] = u[r];
+            }
+            FN(model_step)(a->model, (const REAL *)a->model_par, n, m, x, u, xn);
+            for (int j = 0; j < n; ++j) x[j] = xn[j];
+        }
+    }
+    return ISLS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * SLS-ADMM, control chance constraints: the loop of SLS.ADMM_SLS, isls/sls.py:363-449 (project_u only;
  * f_argmin 375-384, z/lambda update 398-403, Rr-scaled Frobenius residuals 405-412, stop rules 415-430).
  * ------------------------------------------------------------------------------------------- */

@@ -819,7 +819,8 @@ def gen_isls_admm():
     A_, b_ = robust_control_rows(q_dim, upper, lower, var_x0, psi_inv)
     out.update(upper=np.array(upper), lower=np.array(lower), var_x0=np.array(var_x0), psi_inv=np.array(psi_inv))
     res = {k_: [] for k_ in ("du", "phi_u", "x_nom", "u_nom", "cost_log", "n_outer", "unc_du", "unc_phi_u", "unc_cost_log",
-                             "proj_in", "proj_out", "n_proj")}
+                             "proj_in", "proj_out", "n_proj", "ctl_k", "ctl_K_probe", "mc_x0", "mc_x", "mc_u")}
+    probe = np.random.default_rng(5).standard_normal(N * 9)
     for b in range(2):
         calls_in, calls_out = [], []
 
@@ -846,6 +847,15 @@ def gen_isls_admm():
         print("isls_admm problem", b, "cost log", obj.cost_log, "projection calls", len(calls_in))
         res["du"].append(du), res["phi_u"].append(phi_u), res["x_nom"].append(obj.x_nom.copy()), res["u_nom"].append(obj.u_nom.copy())
         res["cost_log"].append(np.array(obj.cost_log, dtype=float)[:4]), res["n_outer"].append(len(obj.cost_log) - 1)
+        # controller of the notebook's cells 23 / 26 (SLS.controller on the iSLS object's Sw, Su) and its Monte-Carlo closed loop
+        PHI_U = np.zeros((3 * N, 9 * N))
+        PHI_U[:, :q_dim] = phi_u
+        K_sls, k_sls = ref.SLS.controller(obj, PHI_U, du)
+        x0s = np.tile(obj.x_nom[0:1], (8, 1))
+        x0s[:, :q_dim] += np.sqrt(var_x0) * np.random.default_rng(7 + b).standard_normal((8, q_dim))
+        x0s[:, 6:] = P.arm_fk(x0s[:, :q_dim])
+        mx, mu = obj.get_trajectory_sls(x0s, K_sls, k_sls)
+        res["ctl_k"].append(k_sls), res["ctl_K_probe"].append(K_sls @ probe), res["mc_x0"].append(x0s), res["mc_x"].append(mx), res["mc_u"].append(mu)
         # arguments and results of the projection during the first outer iteration (one call per ADMM iteration)
         res["proj_in"].append(np.stack(calls_in[:10])), res["proj_out"].append(np.stack(calls_out[:10])), res["n_proj"].append(len(calls_in))
     out.update(x0=cfg["x0"], **{k_: np.stack(v) for k_, v in res.items()})

@@ -62,6 +62,16 @@ def test_dense_oracle_matches_reference(oracle, golden):
         assert rel(du, g["du"][b]) < 1e-9 and rel(phi, g["phi_u"][b]) < 1e-9
         assert rel(d.cost_log, g["cost_log"][b]) < 1e-10
         assert rel(d.x_nom, g["x_nom"][b]) < 1e-10 and rel(d.u_nom, g["u_nom"][b]) < 1e-10
+        # controller + Monte-Carlo closed loop of the notebook (cells 23 / 26).  The reference returns only the FIRST of the
+        # M trajectories for a batch of initial states (inverted `x0.ndim` test, isls_base.py:39-42); g9 holds that one.
+        from oracle.isls_admm_dense import controller
+        K, k = controller(d.Sw, d.Su, phi, du, 9)
+        probe = np.random.default_rng(5).standard_normal(40 * 9)
+        assert rel(K @ probe, g["ctl_K_probe"][b]) < 1e-8 and rel(k, g["ctl_k"][b]) < 1e-8
+        x0 = np.ascontiguousarray(g["mc_x0"][b])
+        xl, ul = np.zeros((8, 40, 9)), np.zeros((8, 40, 3))
+        oracle.dense_closed_loop(pa["model"], pa["model_par"], np.ascontiguousarray(K), k, x0, xl, ul, xhat=d.x_nom.copy(), uhat=d.u_nom.copy())
+        assert rel(xl[0], g["mc_x"][b]) < 1e-8 and rel(ul[0], g["mc_u"][b]) < 1e-8
 
 
 def test_transfer_matrices_reproduce_rollout(oracle):
@@ -213,6 +223,21 @@ def test_isls_admm_robust_control_bounds(oracle, golden):
         assert len(d.logs[-1]) == s.admm_iters[b]
         assert rel(s.admm_logs[:s.admm_iters[b], b], np.array(d.logs[-1])) < 1e-6
     assert (s.outer_iters == g["n_outer"]).all()
+    # controller + Monte-Carlo closed loop (notebook cells 23 / 26) against the reference's outputs and the oracle
+    PHI_U = np.zeros((2, 120, 360))
+    PHI_U[:, :, :3] = phi
+    K, k = s.controller(PHI_U, du)
+    probe = np.random.default_rng(5).standard_normal(40 * 9)
+    pa = problem_arrays(cfg, [0])
+    for b in range(2):
+        assert rel(K[b] @ probe, g["ctl_K_probe"][b]) < 1e-7 and rel(k[b], g["ctl_k"][b]) < 1e-7
+        x, u = s.get_trajectory_sls(g["mc_x0"][b], K[b], k[b], problem=b)
+        assert x.shape == (8, 40, 9) and u.shape == (8, 40, 3)
+        assert rel(x[0], g["mc_x"][b]) < 1e-7 and rel(u[0], g["mc_u"][b]) < 1e-7
+        xl, ul = np.zeros((8, 40, 9)), np.zeros((8, 40, 3))
+        oracle.dense_closed_loop(pa["model"], pa["model_par"], np.ascontiguousarray(K[b]), np.ascontiguousarray(k[b]),
+                                 np.ascontiguousarray(g["mc_x0"][b]), xl, ul, xhat=s.x_nom[b].copy(), uhat=s.u_nom[b].copy())
+        assert rel(x, xl) < 1e-10 and rel(u, ul) < 1e-10
 
 
 @pytest.mark.gpu
