@@ -84,9 +84,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories in the CPU-baseline sample (0: auto)")
     ap.add_argument("--config5", action="store_true", help="secondary workload: SLS-ADMM with chance constraints (B=8192, N=50)")
     ap.add_argument("--config5-dim", type=int, default=1, help="double integrator dimension of the config-5 workload (1 or 3)")
+    ap.add_argument("--isls-admm", action="store_true", help="secondary workload: iSLS.isls_admm on the 3R arm with robust control bounds")
     args = ap.parse_args()
     if args.config5:
         return config5_main(args)
+    if args.isls_admm:
+        return isls_admm_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -314,6 +317,65 @@ def config5_main(args):
             # problems whose bound is infeasible do not contract and amplify rounding differences: median and max
             out["rel_diff_vs_oracle_on_sample"] = {"median": float(np.median(d)), "max": float(np.max(d))}
         print(json.dumps(out))
+
+
+# ---- iSLS.isls_admm: secondary workload, `--isls-admm` ---------------------------------------------------------
+def isls_admm_main(args):
+    """`bench.py --isls-admm`: the robust-control notebook's call (3R arm, chance constraint on the controls with respect to
+    the initial joint angles, dim = 3, 10 ADMM iterations, 30 line-search candidates) for a batch of arms that differ in
+    their initial configuration; outer iterations per second over the whole batch, the dense numpy oracle timed beside it
+    on a few problems."""
+    import isls
+    import isls_problems as P
+    from isls import models
+    from isls.projections import chance_constraint_rows
+    from scipy.stats import norm
+    torch.cuda.set_device(0)
+    B, N = (args.batch if args.batch != 4096 else 1024), args.horizon
+    J, L, outer = 10, 30, max(1, args.steps // 5)
+    cfg = P.config3(batch=B, N=N, seed=0)
+    cfg["u0"] = np.zeros_like(cfg["u0"])
+    cs = chance_constraint_rows(3, 6.0, -6.0, 0.1, float(norm.ppf(0.82)), rho=10.0, max_iter=100, threshold=1e-4)
+
+    def fresh(bsel):
+        s = isls.iSLS(cfg["n"], cfg["m"], N, batch=len(bsel))
+        s.forward_model = models.Planar3R(cfg["dt"])
+        s.set_cost_variables(cfg["zs"], cfg["Qs"], cfg["seq"], cfg["u_std"])
+        xs, us = zip(*[P.initial_nominal(cfg, b) for b in bsel])
+        s.reset()
+        s.nominal_values = np.stack(xs), np.stack(us)
+        return s
+    s = fresh(range(B))
+    s.isls_admm(3, None, max_line_search=L, k_max=1, project_u=cs, rho_u=1.0, max_admm_iter=J, threshold=0.0)     # warm-up
+    s = fresh(range(B))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.isls_admm(3, None, max_line_search=L, k_max=outer, project_u=cs, rho_u=1.0, max_admm_iter=J, threshold=0.0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    done = float(np.mean(s.outer_iters))
+    out = {"metric": "isls_admm outer iterations/sec (3R arm, robust control bounds)", "value": done / dt, "unit": "iterations/s",
+           "n_gpus": 1, "dtype": "f64", "data": "synthetic", "higher_is_better": True,
+           "config": {"workload": "isls_admm: 3R arm, chance constraint on u w.r.t. q0 (dim 3)", "batch": B, "horizon": N,
+                      "admm_iters_J": J, "line_search_L": L, "outer_iterations_run": done},
+           "ms_per_outer_iteration": 1e3 * dt / done, "problem_iterations_per_s": B * done / dt,
+           "final_cost_mean": float(np.mean(s.cost))}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import problem_arrays
+        from oracle import oracle as orc
+        from oracle.isls_admm_dense import DenseIslsAdmm, shifted_sets_projection
+        okern, olib = orc.load()
+        orc.set_threads(olib, 1)
+        sample = 2
+        t0 = time.perf_counter()
+        for b in range(sample):
+            d = DenseIslsAdmm(okern, problem_arrays(cfg, [b]), 3, project_u=shifted_sets_projection(okern, cs), rho_u=1.0, threshold=0.0)
+            d.solve(1, J, L)
+        dtc = (time.perf_counter() - t0) / sample
+        out["cpu_baseline"] = {"value": 1.0 / (dtc * B), "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "sample": f"{sample} problems x 1 outer iteration of the dense numpy restatement, scaled linearly to {B}"}
+    print(json.dumps(out))
 
 
 def host_cores():
