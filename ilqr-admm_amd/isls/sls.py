@@ -19,7 +19,7 @@ Config 5 of BASELINE.json (system level synthesis with chance constraints on the
     controller / get_trajectory_sls K = Phi_u Phi_x^-1 (host set-up) and the closed-loop Monte-Carlo rollout (device)
                                                                                             (isls/sls.py:235-242, sls_base.py:91-105)
 
-The remaining dense batch-form solvers (solve_batch, ADMM_LQT_Batch, replanning) raise NotImplementedError.
+solve_batch / ADMM_LQT_Batch return the batch form's results through the same Riccati kernels; replanning raises.
 """
 import numpy as np
 import torch
@@ -129,9 +129,13 @@ class SLS(Base):
         return self._out(e.k)
 
     def solve(self, x0=None, method='sls'):
+        """isls/sls.py:40-58."""
+        if method == 'batch':
+            assert x0 is not None
+            return self.solve_batch(x0)
         if method == 'dp':
             return self.solve_dp()
-        raise NotImplementedError("only method='dp' is built (batch / sls forms: config 5, later round)")
+        return self.solve_sls()
 
     def get_trajectory_dp(self, x0, K, k, noise_scale=0):
         """u_t = K_t x_t + k_t, x_{t+1} = A x_t + B u_t  (isls/sls_base.py:76-89).  x0 [n] -> one trajectory per problem
@@ -158,6 +162,24 @@ class SLS(Base):
                     tol=1e-3, verbose=False, log=False):
         """isls/sls.py:298-317: gain pass once, then ADMM iterations of [ff pass, closed-loop rollout from x0,
         z/lambda update] with the stop rules of isls/admm.py:72-85.  Returns (x_flat, u_flat, K, k[, logs])."""
+        return self._admm_lqt(x0, project_x, project_u, max_iter, rho_x, rho_u, alpha, tol, log, batch_form=False)
+
+    def ADMM_LQT_Batch(self, x0, project_x=False, project_u=False, max_iter=20, rho_x=None, rho_u=None, alpha=1.,
+                       tol=1e-3, verbose=False, log=False):
+        """isls/sls.py:252-293 without its dense (N m)^2 algebra: the batch-form x-step
+        u = (Su'Q Su + R + Su'Qr Su + Rr)^-1 (...) is the minimiser the Riccati pass computes, except for the last control,
+        which never acts on the state and which the dense form sets to (R + Rr)^-1 Rr (z_u - lmb_u) at t = N-1 (SURVEY 8a
+        quirk i); z starts at the unconstrained solution (sls.py:268-270).  Returns (x_flat, u_flat[, logs])."""
+        out = self._admm_lqt(x0, project_x, project_u, max_iter, rho_x, rho_u, alpha, tol, log, batch_form=True)
+        return out[:2] + out[4:]
+
+    def solve_batch(self, x0):
+        """isls/sls.py:60-82: the unconstrained batch-form LQT solution equals the Riccati solution rolled out from x0 (the
+        last control is zero in both forms: its only cost term is u'Ru).  Returns (x_opt [N,n], u_opt [N,m])."""
+        K, k = self.solve_dp()
+        return self.get_trajectory_dp(x0, K, k)
+
+    def _admm_lqt(self, x0, project_x, project_u, max_iter, rho_x, rho_u, alpha, tol, log, batch_form):
         e = self.engine
         B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
         px, pu = self._projection(project_x, n), self._projection(project_u, m)
@@ -182,6 +204,17 @@ class SLS(Base):
         x0t = e._t(self._batched(x0, 1))
         one = torch.ones(1, dtype=e.dtype, device=e.device)
         stream = torch.cuda.current_stream().cuda_stream
+        last = None
+        if batch_form:
+            # z <- unconstrained solution (sls.py:266-270); the caller's regularised factors are rebuilt right after
+            xs, us = self.solve_batch(x0)
+            self.solve_dp(Rr=Rr, Qr=Qr, xr=np.zeros(N * n), ur=np.zeros(N * m))
+            if e.zx is not None:
+                e.zx.copy_(e._t(np.asarray(xs).reshape(B, N, n)))
+            if e.zu is not None:
+                e.zu.copy_(e._t(np.asarray(us).reshape(B, N, m)))
+                R_, Rr_ = np.eye(m) * self.u_std, np.asarray(Rr[-1], dtype=np.float64)
+                last = e._t(np.ascontiguousarray((np.linalg.inv(R_ + Rr_) @ Rr_).T))      # u_{N-1} = (z - lmb)_{N-1} @ last
         e.res_prev.fill_(1e6)
         e.admm_active.fill_(1)
         e.admm_iters.zero_()
@@ -196,6 +229,9 @@ class SLS(Base):
                 e.kern.rollout_ls(e.model, e.model_par, e.K, e.k, e.xhat, e.uhat, one, e.Qtab, e.ztab, e.seq, e.u_std,
                                   e.xx, e.xu, x0=x0t, flags=capi.RO_ABSOLUTE, q_nonzero=e.q_nonzero,
                                   active=e.admm_active, stream=stream)
+                if last is not None:                              # the dense form's last control (see ADMM_LQT_Batch)
+                    on = e.admm_active.to(torch.bool).view(B, 1)
+                    e.xu[:, N - 1] = torch.where(on, (e.zu[:, N - 1] - e.lu[:, N - 1]) @ last, e.xu[:, N - 1])
                 e.kern.admm_update(e.xx, e.xu, e.res, zx=e.zx, lx=e.lx, zu=e.zu, lu=e.lu,
                                    x_lo=e.x_lo if isinstance(px, Box) else None, x_hi=e.x_hi if isinstance(px, Box) else None,
                                    u_lo=e.u_lo if isinstance(pu, Box) else None, u_hi=e.u_hi if isinstance(pu, Box) else None,
@@ -307,8 +343,6 @@ class SLS(Base):
 
     # ---- out of scope (dense batch-form LQT) ------------------------------------------------------------------------
     def _dense_batch_form(self, *a, **k):
-        raise NotImplementedError("dense batch-form LQT solvers (solve_batch, ADMM_LQT_Batch, replanning) are not built; "
-                                  "the DP-form methods solve the same problems")
+        raise NotImplementedError("replanning and open-loop batch rollouts of the dense batch form are not built")
 
-    solve_batch = ADMM_LQT_Batch = _dense_batch_form
     initialize_replanning_procedure = replan_feedforward = get_trajectory_batch = _dense_batch_form

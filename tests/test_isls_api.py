@@ -70,6 +70,30 @@ def test_sls_dp_and_admm_lqt_dp(golden, tag, N):
     assert np.array_equal(xs[7], x1) and np.array_equal(us[7], u1)
 
 
+@pytest.mark.parametrize("tag,N", [("n50", 50), ("n100", 100)])
+def test_sls_batch_form_through_the_riccati_pass(golden, tag, N):
+    """solve_batch / ADMM_LQT_Batch (config 1's second oracle, isls/sls.py:60-82,252-293) against the unmodified reference.
+    The reference solves dense normal equations (Su'Q Su + R, Q = 1e6, R = 1e-2: condition number ~1e9), ours is the
+    Riccati pass + the dense form's last control; the two agree to the accuracy of the reference's own dense solve."""
+    import isls
+    g = golden("g1_di1d_lqt.npz")
+    c = P.config1(N)
+    sls = isls.SLS(2, 1, N)
+    sls.AB = [c["A"], c["B"]]
+    sls.set_quadratic_cost(c["zs"], c["Qs"], c["seq"], c["u_std"])
+    x, u = sls.solve(c["x0"], method="batch")
+    assert x.shape == (N, 2) and u.shape == (N, 1)
+    assert rel(x, g[f"{tag}_batch_x"]) < 1e-7 and rel(u, g[f"{tag}_batch_u"]) < 1e-7
+    xb, ub, logs = sls.ADMM_LQT_Batch(x0=c["x0"], project_u=lambda v: isls.project_bound(v, c["u_lo"], c["u_hi"]), max_iter=100,
+                                      rho_u=1e-2, tol=1e-4, verbose=False, log=True)
+    gl = g[f"{tag}_admm_batch_logs"]
+    assert len(logs) == len(gl)                                    # n100: 20 iterations, the notebook's count
+    assert rel(np.stack(logs), gl) < 1e-6
+    assert rel(ub, g[f"{tag}_admm_batch_u"]) < 1e-7
+    if N == 100:
+        assert abs(np.max(ub) - 5.000018035934772) < 1e-7          # control bounds.ipynb:204-207
+
+
 # ---------------------------------------------------------------------------------------------------------
 # iSLS: kernels through the class surface
 # ---------------------------------------------------------------------------------------------------------
