@@ -93,8 +93,11 @@ class Engine:
 
     # ---- problem setup ---------------------------------------------------------------------------------
     def _t(self, x):
-        return torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=self.dtype,
-                               device=self.device).contiguous()
+        if not isinstance(x, torch.Tensor):
+            x = np.asarray(x)
+            if not x.flags.writeable:                          # broadcast views: torch wants an array it may alias
+                x = x.copy()
+        return torch.as_tensor(x, dtype=self.dtype, device=self.device).contiguous()
 
     def set_model(self, model_id, par):
         """Built-in forward model (ISLS_MODEL_*); par is [P] (shared) or [B,P] (per trajectory)."""

@@ -9,6 +9,7 @@ numerical step runs in the HIP kernels behind `engine.Engine`:
     iterate_once_dp   -> gain, ff, rollout_ls(NaN rule, acceptance test)   (isls/isls.py:336-374)
     ilqr_admm         -> DP form: ilqr_admm_outer + accept_step            (isls/isls.py:379-501, "TODO: add dp solution")
     isls_admm         -> DP form: gain + C x ff + columns_rollout + rollout_ls + columns_admm (isls/isls.py:503-712)
+    backward_pass_batch / iterate_once_batch -> gain + ff + columns_rollout (column 0) + open-loop rollout_ls (isls.py:156-228)
 
 Differences from the reference, all deliberate and documented in DESIGN.md: `ilqr_admm` uses the DP (Riccati)
 solve instead of the dense batch-form least squares (identical iterates except the never-applied last control,
@@ -163,6 +164,7 @@ class iSLS(Base):
             e.expand()
             return
         n = self.x_dim
+        e.allow_shared_hessian = False                          # the caller's Hessians differ per trajectory
         Cts, cts = self._batched(Cts, 3), self._batched(cts, 2)
         e.Cxx.copy_(e._t(Cts[..., :n, :n])), e.Cuu.copy_(e._t(Cts[..., n:, n:]))
         e.Cux = e._t(Cts[..., n:, :n])
@@ -222,8 +224,8 @@ class iSLS(Base):
     def solve(self, get_AB=None, get_Cs=None, is_dynamics_linear=False, is_cost_quadratic=False, method='dp',
               max_iter=100, max_line_search_iter=25, tol_fun=1e-5, tol_grad=1e-4, verbose=False):
         """iLQR outer loop with the reference's stop rules (isls/isls.py:54-132), per trajectory when batched."""
-        if method != 'dp':
-            raise NotImplementedError("only method='dp' is built for MI355X (batch form is O((N m)^3) dense algebra)")
+        if method not in ('dp', 'batch'):
+            raise NotImplementedError("method must be 'dp' or 'batch' (the reference raises for 'sls' too, isls.py:121-122)")
         e = self.engine
         e.outer_active.fill_(1)
         prev = np.atleast_1d(np.array(self.cost, dtype=np.float64)).copy()
@@ -234,8 +236,13 @@ class iSLS(Base):
                 self._linearize(get_AB)
             Cts = cts = None
             self._check_get_Cs(get_Cs)
-            ok, _, _ = self.iterate_once_dp(max_line_search=max_line_search_iter, verbose=verbose, Cts=Cts, cts=cts,
-                                            _linearized=True)
+            if method == 'dp':
+                ok, _, _ = self.iterate_once_dp(max_line_search=max_line_search_iter, verbose=verbose, Cts=Cts, cts=cts,
+                                                _linearized=True)
+            else:
+                self._user_AB, keep = True, self._user_AB         # linearised above: backward_pass_batch must not redo it
+                ok = self.iterate_once_batch(max_line_search=max_line_search_iter, Cts=Cts, cts=cts, verbose=verbose)
+                self._user_AB = keep
             cur = np.atleast_1d(np.array(self.cost, dtype=np.float64))
             okv = np.atleast_1d(ok)
             act = e.outer_active.cpu().numpy().astype(bool)
@@ -264,9 +271,7 @@ class iSLS(Base):
 
     def solve_ilqr(self, get_AB=None, max_ilqr_iter=100, max_line_search_iter=25, dp=True, verbose=False, **kw):
         """Notebook-era name (Car notebooks :254): iLQR with the quadratic cost set by set_cost_variables."""
-        if not dp:
-            raise NotImplementedError("batch-form iLQR (dp=False) is out of scope; use dp=True")
-        return self.solve(get_AB, method='dp', max_iter=max_ilqr_iter, max_line_search_iter=max_line_search_iter,
+        return self.solve(get_AB, method='dp' if dp else 'batch', max_iter=max_ilqr_iter, max_line_search_iter=max_line_search_iter,
                           verbose=verbose, **kw)
 
     # ---- iLQR-ADMM (DP form) --------------------------------------------------------------------------------
@@ -412,10 +417,62 @@ class iSLS(Base):
         x, u = x_log.cpu().numpy().astype(np.float64), u_log.cpu().numpy().astype(np.float64)
         return (x[0], u[0]) if single else (x, u)
 
-    def rollout_batch(self, *a, **k):
-        raise NotImplementedError("batch-form iLQR is out of scope (SURVEY 2, row 10); use the DP form")
+    # ---- batch-form iLQR (isls/isls.py:135-228) through the Riccati kernels ---------------------------------------------
+    def rollout_batch(self, x_nom, u_nom):
+        """Open-loop rollouts from x_nom[0] (isls/isls.py:135-154): u_nom [L,N,m] (or [B,L,N,m]) -> (x_log, u_nom)."""
+        e = self.engine
+        u = np.asarray(u_nom, dtype=np.float64)
+        ub = u if (self.batch > 1 and u.ndim == 4) else np.broadcast_to(u[None], (self.batch,) + u.shape)
+        x0 = e._t(self._batched(np.asarray(x_nom, dtype=np.float64), 2)[:, 0].copy())
+        zero_K = torch.zeros(self.batch, self.N, self.u_dim, self.x_dim, dtype=e.dtype, device=e.device)
+        zero_u = torch.zeros(self.batch, self.N, self.u_dim, dtype=e.dtype, device=e.device)
+        one = torch.ones(1, dtype=e.dtype, device=e.device)
+        xs = []
+        for l in range(ub.shape[1]):
+            e.kern.rollout_ls(e.model, e.model_par, zero_K, e._t(np.ascontiguousarray(ub[:, l])), e.xhat, zero_u, one, e.Qtab, e.ztab,
+                              e.seq, e.u_std, e.xx, e.xu, x0=x0, q_nonzero=e.q_nonzero, cost_model=e.cost_model, cost_par=e.cost_par,
+                              stream=torch.cuda.current_stream().cuda_stream)
+            xs.append(e.xx.cpu().numpy())
+        x = np.stack(xs, axis=1)
+        return (x[0] if self.batch == 1 else x), u
 
-    backward_pass_batch = iterate_once_batch = rollout_batch
+    def backward_pass_batch(self, Cts=None, cts=None):
+        """delta_u_opt [N,m] of the batch-form least squares (isls/isls.py:156-189): the minimiser of the LQ sub-problem
+        about the nominal, i.e. the Riccati solution rolled through the linearised dynamics, plus the dense form's last
+        control (column 0 of isls_columns_rollout; SURVEY 8a quirk i)."""
+        e = self.engine
+        if not self._user_AB:
+            self._linearize(None)
+        self._expand(Cts, cts)
+        e.gain()
+        z = lambda *s_: torch.zeros(*s_, dtype=e.dtype, device=e.device)        # noqa: E731
+        B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
+        kcol, dx, du = z(2, B, N, m), z(2, B, N, n), z(2, B, N, m)
+        e.kern.riccati_ff(e.A, e.Bm, e.c0x, e.c0u, e.K, e.Quu, e.fac, e.Qux, kcol[0], solve_mode=e.solve_mode,
+                          stream=torch.cuda.current_stream().cuda_stream)
+        e.kern.columns_rollout(e.A, e.Bm, e.hessians()[1], e.c0u, e.K, kcol, dx, du, stream=torch.cuda.current_stream().cuda_stream)
+        self._du_batch = du[0]
+        return self._out(du[0])
+
+    def iterate_once_batch(self, verbose=False, max_line_search=15, **kwargs):
+        """Batch-form backward pass + open-loop line search with the acceptance test costs[ind] < cost
+        (isls/isls.py:191-225).  Returns fp_success (bool, or a bool array when batched)."""
+        e = self.engine
+        self.backward_pass_batch(**kwargs)
+        zero_K = torch.zeros(self.batch, self.N, self.u_dim, self.x_dim, dtype=e.dtype, device=e.device)
+        e.status.zero_()
+        e.kern.rollout_ls(e.model, e.model_par, zero_K, self._du_batch, e.xhat, e.uhat, e.alphas[:max_line_search], e.Qtab, e.ztab,
+                          e.seq, e.u_std, e.xx, e.xu, best=e.best, cost_new=e.cost_new, cost_cur=e.cost, flags=capi.RO_ACCEPT_TEST,
+                          status=e.status, active=e.outer_active, q_nonzero=e.q_nonzero, cost_model=e.cost_model,
+                          cost_par=e.cost_par, stream=torch.cuda.current_stream().cuda_stream)
+        ok = (e.status.cpu().numpy() & capi.ST_LS_REJECT) == 0
+        e.accept_x_step()
+        if self.batch == 1:
+            if ok[0]:
+                self.cost_log.append(self.cost)
+            return bool(ok[0])
+        self.cost_log.append(self.cost)
+        return ok
 
     # ---- closed-loop evaluation (isls/isls_base.py:62-71) -----------------------------------------------------
     def get_trajectory_dp(self, x0, K, k, noise_scale=0):

@@ -862,8 +862,38 @@ def gen_isls_admm():
     save("g9_isls_admm.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G10: batch-form iLQR of iSLS (backward_pass_batch / iterate_once_batch / solve(method='batch'), isls/isls.py:156-228,
+# shimmed) on the 3R arm and the car
+# ---------------------------------------------------------------------------------------------
+def gen_batch_ilqr():
+    import contextlib
+    import io
+    out = {}
+    for name, cfg in (("arm", P.config3(batch=2, N=40, seed=3)), ("car", P.config4(batch=2, N=60, seed=2))):
+        res = {k_: [] for k_ in ("du0", "cost_log", "n_it", "x_fin", "u_fin")}
+        for b in range(2):
+            obj, get_AB = make_ref_isls(cfg, b)
+            obj.AB = get_AB(obj.x_nom, obj.u_nom)
+            res["du0"].append(obj.backward_pass_batch())
+            # HEAD's solve() calls get_Cs unconditionally, so the quadratic-cost problem runs through the loop of
+            # isls.py:106-132 written out here (the notebook-era solve_ilqr(dp=False))
+            with contextlib.redirect_stdout(io.StringIO()):
+                for i in range(6):
+                    obj.AB = get_AB(obj.x_nom, obj.u_nom)
+                    ok = obj.iterate_once_batch(max_line_search=20)
+                    if np.abs(np.diff(obj.cost_log[-2:])) < 1e-5 or not ok:
+                        break
+            cl = np.full(8, np.nan)
+            cl[:len(obj.cost_log)] = obj.cost_log
+            res["cost_log"].append(cl), res["n_it"].append(len(obj.cost_log)), res["x_fin"].append(obj.x_nom.copy()), res["u_fin"].append(obj.u_nom.copy())
+            print("batch iLQR", name, b, obj.cost_log)
+        out.update({f"{name}_{k_}": np.stack(v) for k_, v in res.items()})
+    save("g10_batch_ilqr.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm"]
+    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm", "batch_ilqr"]
     for w in which:
         {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections, "sls": gen_sls,
-         "tassa": gen_tassa, "isls_admm": gen_isls_admm}[w]()
+         "tassa": gen_tassa, "isls_admm": gen_isls_admm, "batch_ilqr": gen_batch_ilqr}[w]()

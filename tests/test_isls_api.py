@@ -149,6 +149,28 @@ def test_isls_solve_cost_logs(golden, which):
 # ---------------------------------------------------------------------------------------------------------
 # iSLS.ilqr_admm (DP form) against the reference-composed O2 traces
 # ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["arm", "car"])
+def test_isls_batch_form_ilqr(golden, name):
+    """backward_pass_batch / iterate_once_batch / solve(method='batch') (isls/isls.py:156-228) against the reference's dense
+    least squares (G10).  The reference solves normal equations with condition number ~1e10 (arm: Q = 1e6, R = 1e-4), so its
+    own delta_u carries ~1e-6 relative error; the cost logs agree much better because the minimiser is flat there."""
+    g = golden("g10_batch_ilqr.npz")
+    cfg = P.config3(batch=2, N=40, seed=3) if name == "arm" else P.config4(batch=2, N=60, seed=2)
+    s = make_isls(cfg, [0, 1])
+    du0 = s.backward_pass_batch()
+    assert rel(du0, g[f"{name}_du0"]) < 2e-5
+    x_ol, _ = s.rollout_batch(s.x_nom[0], (s.u_nom[0] + du0[0])[None])            # open-loop rollout of one candidate
+    assert x_ol.shape == (2, 1, cfg["N"], cfg["n"]) and np.array_equal(x_ol[0, 0, 0], s.x_nom[0, 0])
+    s.solve(method='batch', max_iter=6, max_line_search_iter=20)
+    logs = np.array(s.cost_log)
+    for b in range(2):
+        n_it = int(g[f"{name}_n_it"][b])
+        mine = logs[:n_it, b]
+        assert rel(mine, g[f"{name}_cost_log"][b][:n_it]) < 1e-6
+        assert (logs[n_it - 1:, b] == logs[n_it - 1, b]).all()                    # stopped where the reference stopped
+        assert rel(s.x_nom[b], g[f"{name}_x_fin"][b]) < 1e-5 and rel(s.u_nom[b], g[f"{name}_u_fin"][b]) < 1e-4
+
+
 def _check_final(s, g, prefix, bsel, n_outer, J, tols):
     e = s.engine
     o = n_outer - 1
@@ -266,7 +288,7 @@ def test_unbuilt_paths_fail_loudly():
     with pytest.raises(NotImplementedError):
         s.forward_model = lambda x, u: x
     with pytest.raises(NotImplementedError):
-        s.rollout_batch(None, None)
+        s.solve(method='sls')
     sl = isls.SLS(2, 1, 20)
     with pytest.raises(NotImplementedError):
         sl.ADMM_SLS()
