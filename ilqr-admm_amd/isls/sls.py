@@ -19,7 +19,8 @@ Config 5 of BASELINE.json (system level synthesis with chance constraints on the
     controller / get_trajectory_sls K = Phi_u Phi_x^-1 (host set-up) and the closed-loop Monte-Carlo rollout (device)
                                                                                             (isls/sls.py:235-242, sls_base.py:91-105)
 
-solve_batch / ADMM_LQT_Batch return the batch form's results through the same Riccati kernels; replanning raises.
+solve_batch / ADMM_LQT_Batch return the batch form's results through the same Riccati kernels; replanning and the
+`*_optimal` helpers are dense host algebra as in the reference.
 """
 import numpy as np
 import torch
@@ -341,8 +342,27 @@ class SLS(Base):
                                stream=torch.cuda.current_stream().cuda_stream)
         return x_log.cpu().numpy().astype(np.float64), u_log.cpu().numpy().astype(np.float64)
 
-    # ---- out of scope (dense batch-form LQT) ------------------------------------------------------------------------
-    def _dense_batch_form(self, *a, **k):
-        raise NotImplementedError("replanning and open-loop batch rollouts of the dense batch form are not built")
+    def get_trajectory_batch(self, x0, us, noise_scale=0):
+        """Open loop: the control sequence us [N,m] applied from every initial state x0 [M,n] (isls/sls_base.py:61-74)."""
+        K = np.zeros((self.N, self.u_dim, self.x_dim))
+        return self.get_trajectory_dp(x0, K, np.asarray(us, dtype=np.float64).reshape(self.N, self.u_dim), noise_scale)
 
-    initialize_replanning_procedure = replan_feedforward = get_trajectory_batch = _dense_batch_form
+    # ---- at optimality / replanning: dense host algebra on the transfer matrices, as in the reference (cold paths) ----------
+    def u_optimal(self, x0, PHI_U, du):
+        """isls/sls_base.py:55-56."""
+        return (np.asarray(PHI_U)[:, :self.x_dim] @ x0 + du).reshape(self.N, -1)[:-1]
+
+    def x_optimal(self, x0, PHI_X, dx):
+        """isls/sls_base.py:58-59."""
+        return (np.asarray(PHI_X)[:, :self.x_dim] @ x0 + dx).reshape(self.N, -1)
+
+    def initialize_replanning_procedure(self, K):
+        """Map from a change of the stacked targets to the change of the feed-forward term (isls/sls.py:244-245)."""
+        Sw, Su = self._transfer()
+        Q, R, _ = self._dense_cost()
+        SuTQ = Su.T @ Q
+        self.replan_matrix = (np.eye(Su.shape[1]) - np.asarray(K) @ Su) @ np.linalg.solve(SuTQ @ Su + R, SuTQ)
+
+    def replan_feedforward(self, k, xd):
+        """isls/sls.py:247-248."""
+        return k + self.replan_matrix.dot(xd - self._dense_cost()[2])

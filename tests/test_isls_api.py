@@ -94,6 +94,34 @@ def test_sls_batch_form_through_the_riccati_pass(golden, tag, N):
         assert abs(np.max(ub) - 5.000018035934772) < 1e-7          # control bounds.ipynb:204-207
 
 
+def test_sls_replanning_and_open_loop_helpers():
+    """initialize_replanning_procedure / replan_feedforward (isls/sls.py:244-248), u_optimal / x_optimal and
+    get_trajectory_batch (isls/sls_base.py:55-74): replanning the feed-forward term for moved targets equals the
+    controller computed from scratch for them."""
+    import isls
+    N = 20
+    c = P.config1(N)
+    sls = isls.SLS(2, 1, N)
+    sls.AB = [c["A"], c["B"]]
+    sls.set_quadratic_cost(c["zs"], c["Qs"], c["seq"], c["u_std"])
+    PHI_U, du = sls.solve_sls()
+    K, k = sls.controller(PHI_U, du)
+    sls.initialize_replanning_procedure(K)
+    Su, (Q, R, xd) = sls.Su, sls._dense_cost()
+    xd2 = xd + np.random.default_rng(3).normal(scale=0.1, size=xd.shape)
+    du2 = np.linalg.solve(Su.T @ Q @ Su + R, Su.T @ Q @ xd2)
+    assert rel(sls.replan_feedforward(k, xd2), (np.eye(N) - K @ Su) @ du2) < 1e-8
+    x0 = np.array([0.3, -0.1])
+    u_opt = sls.u_optimal(x0, PHI_U, du)
+    assert u_opt.shape == (N - 1, 1)
+    xs, us = sls.get_trajectory_batch(x0[None].repeat(3, 0), np.pad(u_opt, ((0, 1), (0, 0))))
+    x = x0.copy()
+    for t in range(N - 1):                                          # the open-loop sequence reproduces x = Sx x0 + Su u
+        assert rel(xs[1, t], x) < 1e-12
+        x = c["A"] @ x + c["B"] @ u_opt[t]
+    assert rel(sls.x_optimal(x0, sls.Sw + Su @ PHI_U, Su @ du)[:N - 1], xs[0, :N - 1]) < 1e-9
+
+
 # ---------------------------------------------------------------------------------------------------------
 # iSLS: kernels through the class surface
 # ---------------------------------------------------------------------------------------------------------
