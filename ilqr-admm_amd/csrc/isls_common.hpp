@@ -165,6 +165,7 @@ __device__ __forceinline__ float py_mod(float a, float b)
 // Launch wrappers implemented one per .hip file; each returns ISLS_OK / ISLS_ERR_*.
 template <typename T> int launch_gain(const isls_gain_args &a, hipStream_t s);
 template <typename T> int launch_ff(const isls_ff_args &a, hipStream_t s);
+template <typename T> int launch_ff_record(const isls_ff_args &a, hipStream_t s);
 template <typename T> int launch_ff_prepare(const isls_ff_prepare_args &a, hipStream_t s);
 template <typename T> int launch_ff_stitch(const isls_ff_args &a, hipStream_t s);
 bool ff_seg_enabled(const isls_ffseg &sg);

@@ -31,6 +31,7 @@ struct GainP {
     int B, N, mode;
     View<T> A, Bm, Cxx, Cuu, Cux;
     T *K, *Quu, *fac, *Qux;
+    T *rec;                        // nullable: packed step records [Phi | B | K | fac] for riccati_ffrec_kernel
     int32_t *status;
     const int32_t *active;
 };
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     constexpr int DUMP_OFF = K_OFF + NU * NX;              // W words that absorb the LDS writes of lanes with nothing to publish
     constexpr int SLOT = ((DUMP_OFF + W) | 1);             // odd stride: slots start on different banks
     constexpr int JA = (NX * NX + G - 1) / G, JB = (NX * NU + G - 1) / G, JQ = (NU * W + G - 1) / G;
+    constexpr int RB = NX * NX, RK = RB + NX * NU, RFAC = RK + NU * NX, RW = RFAC + NU * NU;   // packed record, see riccati_ffrec.hip
     __shared__ T lds[TPW * SLOT];
 
     const int lane = threadIdx.x;
@@ -213,6 +215,28 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                         v = (i == r) ? vr : v;
                     }
                     p.fac[(o * NU + i) * NU + c] = v;
+                    if (p.rec) p.rec[o * RW + RFAC + i * NU + c] = v;
+                }
+            }
+            // packed record of the feed-forward pass (riccati_ffrec.hip): closed-loop matrix Phi = A + B K (lane i owns
+            // column i, like its column of K), then B, K as they are
+            if (p.rec) {
+                T *ro = p.rec + o * RW;
+                if (xl) {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) {
+                        T ph = ABs[k * W + i];
+#pragma unroll
+                        for (int r = 0; r < NU; ++r) ph += ABs[k * W + NX + r] * Kc[r];
+                        ro[k * NX + i] = ph;
+                    }
+#pragma unroll
+                    for (int r = 0; r < NU; ++r) ro[RK + r * NX + i] = Kc[r];
+                }
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    const int e = i + G * j;
+                    if (e < NX * NU) ro[RB + e] = ABs[(e / NU) * W + NX + (e % NU)];
                 }
             }
         }
@@ -268,7 +292,7 @@ int launch_gain(const isls_gain_args &a, hipStream_t s)
     GainP<T> p;
     p.B = a.B; p.N = a.N; p.mode = a.solve_mode;
     p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.Cxx = View<T>(a.Cxx); p.Cuu = View<T>(a.Cuu); p.Cux = View<T>(a.Cux);
-    p.K = (T *)a.K; p.Quu = (T *)a.Quu; p.fac = (T *)a.fac; p.Qux = (T *)a.Qux;
+    p.K = (T *)a.K; p.Quu = (T *)a.Quu; p.fac = (T *)a.fac; p.Qux = (T *)a.Qux; p.rec = (T *)a.rec;
     p.status = a.status; p.active = a.active;
 #define CALL(NX_, NU_)                                                                                     \
     {                                                                                                      \

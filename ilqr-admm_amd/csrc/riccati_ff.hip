@@ -311,6 +311,15 @@ int launch_ff(const isls_ff_args &a, hipStream_t s)
     if ((int64_t)a.N * a.n * a.n * 64 >= ((int64_t)1 << 31) || a.A.sb * 64 >= ((int64_t)1 << 31) || a.Bm.sb * 64 >= ((int64_t)1 << 31))
         return ISLS_ERR_UNSUPPORTED;
     if (a.B == 0) return ISLS_OK;
+    if (a.rec) {                                               // packed records of the gain pass: riccati_ffrec.hip
+        const bool sg = ff_seg_enabled(a.seg) && a.N > 2;
+        if (sg && (a.seg.nseg > 16 || !a.seg.Psi || !a.seg.v || (int64_t)a.seg.nseg * a.seg.seg_len < a.N - 1 ||
+                   (int64_t)(a.seg.nseg - 1) * a.seg.seg_len >= a.N - 1))
+            return ISLS_ERR_ARG;
+        const int rc = launch_ff_record<T>(a, s);
+        if (rc != ISLS_OK || !sg) return rc;
+        return launch_ff_stitch<T>(a, s);
+    }
     FfP<T> p;
     p.B = a.B; p.N = a.N; p.mode = a.solve_mode;
     p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.c0x = View<T>(a.c0x); p.c0u = View<T>(a.c0u);

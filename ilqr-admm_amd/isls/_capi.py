@@ -38,7 +38,7 @@ class GainArgs(C.Structure):
                 ("solve_mode", C.c_int32), ("_pad", C.c_int32),
                 ("A", View), ("Bm", View), ("Cxx", View), ("Cuu", View), ("Cux", View),
                 ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
-                ("status", C.c_void_p), ("active", C.c_void_p)]
+                ("status", C.c_void_p), ("active", C.c_void_p), ("rec", C.c_void_p)]
 
 
 class FfSeg(C.Structure):
@@ -53,7 +53,7 @@ class FfArgs(C.Structure):
                 ("xhat", C.c_void_p), ("uhat", C.c_void_p),
                 ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
                 ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
-                ("k", C.c_void_p), ("active", C.c_void_p), ("seg", FfSeg)]
+                ("k", C.c_void_p), ("active", C.c_void_p), ("seg", FfSeg), ("rec", C.c_void_p)]
 
 
 class FfPrepareArgs(C.Structure):
@@ -304,7 +304,7 @@ class Kernels:
 
     # -- argument builders (also used to fill OuterArgs) --------------------------------------------
     @staticmethod
-    def gain_args(A, Bm, Cxx, Cuu, K, Quu, fac, Qux, Cux=None, solve_mode=SOLVE_CHOL, status=None, active=None):
+    def gain_args(A, Bm, Cxx, Cuu, K, Quu, fac, Qux, Cux=None, solve_mode=SOLVE_CHOL, status=None, active=None, rec=None):
         B, N, m, n = K.shape
         a = GainArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode)
         a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
@@ -313,11 +313,12 @@ class Kernels:
         a.K, a.Quu = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(Quu, (B, N, m, m), "Quu"))
         a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
         a.status, a.active = _ptr(status), _ptr(active)
+        a.rec = _ptr(_dense(rec, (B, N, n * n + 2 * n * m + m * m), "rec"))
         return a
 
     @staticmethod
     def ff_args(A, Bm, c0x, c0u, K, Quu, fac, Qux, k, Qr=None, Rr=None, xhat=None, uhat=None,
-                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None, seg=None):
+                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None, seg=None, rec=None):
         B, N, m, n = K.shape
         a = FfArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode)
         if seg is not None:
@@ -336,6 +337,7 @@ class Kernels:
         a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
         a.k = _ptr(_dense(k, (B, N, m), "k"))
         a.active = _ptr(active)
+        a.rec = _ptr(_dense(rec, (B, N, n * n + 2 * n * m + m * m), "rec"))
         return a
 
     @staticmethod

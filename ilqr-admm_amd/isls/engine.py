@@ -246,15 +246,26 @@ class Engine:
             self.kern.expand_quadratic(self.Qtab, self.ztab[:1] if self.ztab.ndim == 3 else self.ztab, self.seq, self.u_std,
                                        *self._c0_sh, Cxx=Cxx, Cuu=Cuu, Qr=self.Qr, Rr=self.Rr, stream=_stream_ptr())
 
-    def gain(self, active=None):
+    def ff_record(self):
+        """Packed step records [A + B K | B | K | fac] the gain pass writes for the feed-forward passes (isls_gain_args.rec /
+        isls_ff_args.rec), or None when switched off (ISLS_FF_RECORD=0).  Only the drivers that run the gain pass
+        themselves right before the feed-forward passes use it: the records are stale once K / fac are replaced."""
+        if os.environ.get("ISLS_FF_RECORD", "1") == "0":
+            return None
+        if getattr(self, "_ffrec", None) is None:
+            n, m = self.n, self.m
+            self._ffrec = torch.zeros(self.B, self.N, n * n + 2 * n * m + m * m, dtype=self.dtype, device=self.device)
+        return self._ffrec
+
+    def gain(self, active=None, rec=None):
         self.kern.riccati_gain(self.A, self.Bm, *self.hessians(), self.K, self.Quu, self.fac, self.Qux,
-                               Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active,
+                               Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active, rec=rec,
                                stream=_stream_ptr())
 
-    def feedforward(self, active=None, seg=None):
+    def feedforward(self, active=None, seg=None, rec=None):
         self.kern.riccati_ff(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                              Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx,
-                             zu=self.zu, lu=self.lu, solve_mode=self.solve_mode, active=active, seg=seg,
+                             zu=self.zu, lu=self.lu, solve_mode=self.solve_mode, active=active, seg=seg, rec=rec,
                              stream=_stream_ptr())
 
     def rollout(self, L, flags=0, cost_all=None, active=None):
@@ -296,11 +307,12 @@ class Engine:
     def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None, ff_nseg=None):
         """Marshal the argument block of isls_ilqr_admm_outer once; it stays valid while buffers are not re-allocated."""
         K = capi.Kernels
+        rec = self.ff_record()
         gain = K.gain_args(self.A, self.Bm, *self.hessians(), self.K, self.Quu, self.fac, self.Qux, Cux=self.Cux,
-                           solve_mode=self.solve_mode, status=self.status, active=self.admm_active)
+                           solve_mode=self.solve_mode, status=self.status, active=self.admm_active, rec=rec)
         ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                        Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
-                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=self.ff_seg(ff_nseg))
+                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=self.ff_seg(ff_nseg), rec=rec)
         ro = K.rollout_args(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
                             self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,
                             cost_new=self.cost_new, wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx, zu=self.zu,

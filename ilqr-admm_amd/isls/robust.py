@@ -78,7 +78,8 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     for k in range(k_max):
         self._linearize(get_AB)
         e.expand()
-        e.gain(active=e.outer_active)
+        rec = e.ff_record()                                                     # packed step records for the C x J ff passes
+        e.gain(active=e.outer_active, rec=rec)
         seg = e.ff_seg()                                                        # time-parallel feed-forward passes (isls_ffseg)
         if seg is not None:
             e.feedforward_prepare(seg, active=e.outer_active)
@@ -96,7 +97,7 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
                                 e.Qux, kcol[c], Qr=e.Qr if bx is not None else None, Rr=e.Rr if bu is not None else None,
                                 zx=bx["z"][c] if bx is not None else None, lx=bx["l"][c] if bx is not None else None,
                                 zu=bu["z"][c] if bu is not None else None, lu=bu["l"][c] if bu is not None else None,
-                                solve_mode=e.solve_mode, active=act, seg=seg, stream=_stream_ptr())
+                                solve_mode=e.solve_mode, active=act, seg=seg, rec=rec, stream=_stream_ptr())
             kern.columns_rollout(e.A, e.Bm, Cuu, e.c0u, e.K, kcol, dx, du, Rr=e.Rr if bu is not None else None,
                                  zu=bu["z"] if bu is not None else None, lu=bu["l"] if bu is not None else None,
                                  active=act, stream=_stream_ptr())

@@ -7,11 +7,14 @@ from isls import _capi as capi
 
 
 class DualKernels:
-    def __init__(self, oracle, hip, tol=1e-10, int_exact=True, verbose=False, ff_nseg=1):
+    def __init__(self, oracle, hip, tol=1e-10, int_exact=True, verbose=False, ff_nseg=1, ff_record=False):
         self.oracle, self.hip, self.tol, self.int_exact, self.verbose = oracle, hip, tol, int_exact, verbose
         # > 1: the HIP side runs the feed-forward pass in its time-parallel form (isls_ffseg: prepare + segmented
         # recursion + stitch) while the oracle keeps the reference's sequential recursion
         self.ff_nseg = ff_nseg
+        # True: the HIP gain pass also writes the packed step records (isls_gain_args.rec, NaN-filled before) and the HIP
+        # feed-forward passes read those instead of A, B, K, Quu, fac, Qux; the oracle keeps the reference's recursion
+        self.ff_record, self._rec = ff_record, None
         self.max_err = {}
         self.calls = 0
 
@@ -47,6 +50,12 @@ class DualKernels:
         getattr(self.oracle, name)(*args, **kw)
         if name == "riccati_ff" and self.ff_nseg > 1:
             dkw = dict(dkw, seg=self._prepare_segments(dargs, dkw))
+        if self.ff_record and name == "riccati_gain":
+            B, N, m, n = dargs[4].shape
+            self._rec = torch.full((B, N, n * n + 2 * n * m + m * m), float("nan"), dtype=dargs[4].dtype, device="cuda")
+            dkw = dict(dkw, rec=self._rec)
+        if self.ff_record and name == "riccati_ff" and self._rec is not None and self._rec.shape[:2] == dargs[4].shape[:2]:
+            dkw = dict(dkw, rec=self._rec)
         for blk in ("x", "u"):                                 # set descriptors hold pointers: rebuild them on the device
             if dkw.get(blk + "_sets") is not None:
                 spec, work = dkw[blk + "_sets"]._spec, dkw[blk + "_work"]

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def dual(oracle):
     from dual import DualKernels, hip_kernels
-    return lambda tol=1e-10, ff_nseg=1: DualKernels(oracle, hip_kernels(), tol=tol, ff_nseg=ff_nseg)
+    return lambda tol=1e-10, ff_nseg=1, ff_record=False: DualKernels(oracle, hip_kernels(), tol=tol, ff_nseg=ff_nseg,
+                                                                     ff_record=ff_record)
 
 
 def _report(dk):
@@ -174,6 +175,55 @@ def test_time_parallel_feedforward(dual, N, nseg):
         dk.riccati_ff(d.A, d.Bm, d.c0x, d.c0u, d.K, d.Quu, d.fac, d.Qux, d.k, Qr=d.Qr, Rr=d.Rr, xhat=d.xhat,
                       uhat=d.uhat, zx=d.zx, lx=d.lx, zu=d.zu, lu=d.lu, solve_mode=mode, active=d.admm_active)
         assert np.all(d.k[[2, 5]] == 7.0)
+    _report(dk)
+
+
+@pytest.mark.parametrize("which,ff_nseg", [("di3d", 1), ("di3d", 3), ("car", 1), ("car", 4), ("arm", 1), ("arm", 3), ("di1d", 2)])
+def test_feedforward_on_packed_records(dual, golden, which, ff_nseg):
+    """isls_gain_args.rec / isls_ff_args.rec: the gain pass writes [A + B K | B | K | fac] per step and the feed-forward
+    passes evaluate v = cx + K'cu + (A + B K)'v, k = -Quu^-1 (cu + B'v) from those records -- against the oracle's
+    four-term recursion of the reference (isls.py:285-302), whole ADMM traces, sequential and time-parallel, both solve
+    modes (di1d: the SLS inverse mode), frozen trajectories included."""
+    if which == "di1d":                                         # SLS layout: shared LTI A, B (stride-0 views), absolute coordinates
+        from helpers import rho_to_weights
+        c = P.config1(50)
+        N, n, m, B = 50, 2, 1, 3
+        z = lambda *s_: np.zeros(s_)   # noqa: E731
+        Rr, Qr = rho_to_weights(c["rho_u"], N, m), rho_to_weights(0.5, N, n)
+        rng = np.random.default_rng(0)
+        zx, zu = rng.standard_normal((B, N, n)), rng.standard_normal((B, N, m))
+        lx, lu = 0.1 * rng.standard_normal((B, N, n)), 0.1 * rng.standard_normal((B, N, m))
+        for mode in (capi.SOLVE_CHOL, capi.SOLVE_INV):
+            dk = dual(ff_nseg=ff_nseg, ff_record=True)
+            Cxx, Cuu, c0x, c0u = z(B, N, n, n), z(B, N, m, m), z(B, N, n), z(B, N, m)
+            dk.expand_quadratic(c["Qs"], c["zs"], c["seq"], c["u_std"], c0x, c0u, Cxx=Cxx, Cuu=Cuu, Qr=Qr, Rr=Rr)
+            K, Quu, fac, Qux, k = z(B, N, m, n), z(B, N, m, m), z(B, N, m, m), z(B, N, m, n), z(B, N, m)
+            dk.riccati_gain(c["A"], c["B"], Cxx, Cuu, K, Quu, fac, Qux, solve_mode=mode, status=np.zeros(B, dtype=np.int32))
+            dk.riccati_ff(c["A"], c["B"], c0x, c0u, K, Quu, fac, Qux, k, Qr=Qr, Rr=Rr, zx=zx, lx=lx, zu=zu, lu=lu, solve_mode=mode)
+            assert dk._rec is not None
+        _report(dk)
+        return
+    tol = 1e-10
+    if which == "di3d":
+        cfg = P.config2(batch=32, N=100, seed=1)
+        kw = dict(rho_x=0.05, rho_u=cfg["rho_u"], project_x=True, relax=1.5)
+        pa = problem_arrays(cfg, range(13))
+        pa["x_lo"] = np.full((100, 6), -np.inf); pa["x_hi"] = np.full((100, 6), np.inf)
+        pa["x_lo"][:, 3:6], pa["x_hi"][:, 3:6] = -1.2, 1.2
+    elif which == "car":
+        cfg = P.config4(batch=8, N=200, seed=0)
+        kw = dict(rho_u=cfg["rho_u"])
+        pa = problem_arrays(cfg, range(5))
+    else:
+        cfg = P.config3(batch=2, N=100, seed=0)
+        g = golden("g4_arm3r.npz")
+        tol = max(1e-10, 10 * float(np.max(g["o2_sens"])))        # conditioning-aware bound of the arm (see module docstring)
+        kw = dict(rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+        pa = problem_arrays(cfg, range(2))
+    dk = dual(tol=tol, ff_nseg=ff_nseg, ff_record=True)
+    d = OracleDriver(dk, pa, **kw)
+    d.run(3, 10, 4, 1e-3 if which == "di3d" else 0.0)
+    assert dk._rec is not None
     _report(dk)
 
 
