@@ -25,6 +25,7 @@ namespace isls {
 template <typename T>
 struct RoP {
     int B, N, L, flags, nseg, seg_len;
+    int stage_on;                  // winner trajectory collected in LDS and written out in one sweep (it fits the slot)
     const T *par;
     int64_t par_sb;
     const T *K, *k, *xhat, *uhat, *x0, *alphas;
@@ -149,6 +150,15 @@ struct Model<T, 4, 2, ISLS_MODEL_TASSA> {      // Tassa car-parking [x, y, theta
     }
 };
 
+#ifndef ISLS_RO_HOIST
+#define ISLS_RO_HOIST 0   // reading the augmented-Lagrangian operands early: 0.59 -> 0.67 ms (register pressure), kept off
+#endif
+#ifndef ISLS_RO_WD
+#define ISLS_RO_WD 2      // winner operand ring: 2 and 4 iterations ahead measure the same
+#endif
+#ifndef ISLS_RO_SW
+#define ISLS_RO_SW 5
+#endif
 constexpr int kRolloutDepth = 2;   // steps of record elements in flight per lane (D = 2..5 run within 3 %: issue bound; 2 is leanest)
 constexpr int kMaxSeg = 10;        // winner replay: at most this many segments
 
@@ -158,9 +168,21 @@ struct RoLayout {
     static constexpr int O_K = 0, O_XH = O_K + NU * NX, O_RX = O_XH + NX, O_WQ = O_RX + NX, O_KK = O_WQ + NX,
                          O_UH = O_KK + NU, O_RU = O_UH + NU, O_WR = O_RU + NU, REC = O_WR + NU, O_DUMP = REC,
                          RECP = ((REC + 1) | 1);
-    // slot (elements): 2 records | aug[GL] | plain[GL] | model | checkpoints [L+1][nseg][NX] (row L: dump for idle lanes)
+    // slot (elements): aug[GL] | plain[GL] | model | 2 records | checkpoints [L+1][nseg][NX] (row L: dump for idle lanes)
+    //                  | winner staging [nseg][WREC] + dump word
+    // after the search the records and the checkpoints are dead: the winner's trajectory x [N][NX] | u [N][NU] is collected
+    // there (the "stage") before it goes to HBM in one coalesced sweep
     static constexpr int MDL = NX * (NX + NU);                 // model words of the slot ([A B] of an LTI model)
-    __host__ __device__ static constexpr int slot_elems(int L, int GL, int nseg) { return 2 * RECP + 2 * GL + MDL + (L + 1) * nseg * NX + 1; }
+    static constexpr int WREC = NU * NX + NU + NX + NU;        // K_t | k_t | xhat_t | uhat_t: what the winner replay reads per step
+    __host__ __device__ static constexpr int ck_elems(int L, int nseg, int N, bool stage_on)
+    {
+        const int ckp = (L + 1) * nseg * NX + 1, stage = stage_on ? N * (NX + NU) - 2 * RECP + 1 : 0;
+        return ckp > stage ? ckp : stage;
+    }
+    __host__ __device__ static constexpr int slot_elems(int L, int GL, int nseg, int N, bool stage_on)
+    {
+        return 2 * GL + MDL + 2 * RECP + ck_elems(L, nseg, N, stage_on) + nseg * WREC + 1;
+    }
 };
 
 // register budget: two waves per SIMD where a batch of 4096 launches more waves than SIMDs (slots of >= 16 lanes), the whole
@@ -180,7 +202,8 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
 
     const int L = p.L, N = p.N, NSEG = p.nseg, S = p.seg_len;
     const int GL = L > 8 ? L : 8, TPW = kWave / GL;
-    const int SLOT = LY::slot_elems(L, GL, NSEG);
+    const bool stage_on = p.stage_on != 0;
+    const int SLOT = LY::slot_elems(L, GL, NSEG, N, stage_on);
     const int lane = threadIdx.x;
     // lanes beyond TPW*GL join the last slot as extra idle candidate lanes (c >= GL): they help nobody and
     // write only dump words, but need no slot of their own
@@ -192,7 +215,8 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
     const int bb = inbatch ? b : blockIdx.x * TPW;             // idle lanes shadow the block's first trajectory (loads only)
     const int64_t bN = (int64_t)bb * N;
     T *slot = lds + s * SLOT;
-    T *recs = slot, *c_aug = slot + 2 * RECP, *c_pln = c_aug + GL, *mdl = c_pln + GL, *ck = mdl + LY::MDL;
+    T *c_aug = slot, *c_pln = c_aug + GL, *mdl = c_pln + GL, *recs = mdl + LY::MDL, *ck = recs + 2 * RECP;
+    T *stage = recs;                                           // winner trajectory, over the dead records + checkpoints
     const bool absolute = (p.flags & ISLS_RO_ABSOLUTE) != 0;
     const bool has_xh = !absolute && p.xhat != nullptr, has_uh = !absolute && p.uhat != nullptr;
     const bool has_wq = p.wq.p != nullptr, has_wr = p.wr.p != nullptr;
@@ -313,6 +337,17 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
                     ++seg;
                     next_ck += S;
                 }
+                // augmented-Lagrangian operands of this step, read together with the gains: a second LDS round trip in the
+                // middle of the step (the reads sat behind the has_wq / has_wr branches) cost ~100 cycles per step
+                T al_ru[NU], al_wr[NU], al_rx[NX], al_wq[NX];
+#if ISLS_RO_HOIST
+#pragma unroll
+                for (int r = 0; r < NU; ++r) { al_ru[r] = rec[O_RU + r]; al_wr[r] = rec[O_WR + r]; }
+#endif
+#if ISLS_RO_HOIST == 1
+#pragma unroll
+                for (int j = 0; j < NX; ++j) { al_rx[j] = rec[O_RX + j]; al_wq[j] = rec[O_WQ + j]; }
+#endif
                 // u = (x - xhat) K' + alpha k + uhat            (isls.py:328-329)
                 T u[NU];
 #pragma unroll
@@ -361,11 +396,21 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
                 }
                 if (has_wq) {
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) { const T df = x[j] - rec[O_RX + j]; ag1 += (df * df) * rec[O_WQ + j]; }
+                    for (int j = 0; j < NX; ++j) {
+#if ISLS_RO_HOIST != 1
+                        al_rx[j] = rec[O_RX + j]; al_wq[j] = rec[O_WQ + j];
+#endif
+                        const T df = x[j] - al_rx[j]; ag1 += (df * df) * al_wq[j];
+                    }
                 }
                 if (has_wr) {
 #pragma unroll
-                    for (int r = 0; r < NU; ++r) { const T df = u[r] - rec[O_RU + r]; ag1 += (df * df) * rec[O_WR + r]; }
+                    for (int r = 0; r < NU; ++r) {
+#if !ISLS_RO_HOIST
+                        al_ru[r] = rec[O_RU + r]; al_wr[r] = rec[O_WR + r];
+#endif
+                        const T df = u[r] - al_ru[r]; ag1 += (df * df) * al_wr[r];
+                    }
                 }
                 cst = live ? cst1 : cst;                       // dead (padding) steps leave the sums alone
                 cu = live ? cu1 : cu;
@@ -414,60 +459,134 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
         }
     }
 
+#ifdef ISLS_DIAG
+    const unsigned long long targmin_ = __builtin_readcyclecounter();
+    unsigned long long twplan_ = 0;
+#endif
     // ================================ WINNER ==========================================================
     // lane c < NSEG replays steps [c*S, min((c+1)*S, N)) of candidate `ind` from its checkpoint and streams
     // x_t, u_t to HBM (or copies the kept nominal when the acceptance test failed)
-    if (valid && c < NSEG) {
+    //
+    // The replay's operands (K_t, k_t, xhat_t, uhat_t of NSEG different steps per iteration) are fetched by ALL lanes of the
+    // slot, two iterations ahead, and handed over through LDS: fetched by the segment lanes themselves they were ~30
+    // dependent scattered loads per step, one HBM round trip per step -- 45 % of the kernel's time (cycle stamps, B = 4096).
+    {
+        constexpr int WREC = LY::WREC, WJ = 8, WD = ISLS_RO_WD;         // WJ words per lane and iteration (NSEG * WREC <= WJ * GL), WD iterations
+                                                               // in flight: an iteration is short (~500 cycles), HBM is ~3000 away
+        T *wbuf = ck + LY::ck_elems(L, NSEG, N, stage_on);
+        const int wtot = NSEG * WREC;
+        const bool wlane = valid && c < NSEG;
+        const int cs = c < NSEG ? c : 0;
         const T alpha_w = absolute ? T(1) : p.alphas[ind];
-        const int t0 = c * S, t1 = (t0 + S < N) ? t0 + S : N;
+        const int t0 = cs * S, t1 = (t0 + S < N) ? t0 + S : N;
         T xw[NX];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) xw[j] = ck[(ind * NSEG + c) * NX + j];
-        const T *Kp = p.K + (bN + t0) * NU * NX, *kp = p.k + (bN + t0) * NU;
-        const T *xhp = p.xhat ? p.xhat + (bN + t0) * NX : nullptr, *uhp = p.uhat ? p.uhat + (bN + t0) * NU : nullptr;
-        T *xo = p.x_out + (bN + t0) * NX, *uo = p.u_out + (bN + t0) * NU;
-        for (int t = t0; t < t1; ++t) {
-            T Kt[NU * NX], kt[NU], xh[NX], uh[NU];
+        for (int j = 0; j < NX; ++j) xw[j] = ck[(ind * NSEG + cs) * NX + j];
+        const T *wp[WJ];
+        int wst[WJ], wmax[WJ], wdst[WJ];
+        T wm[WJ];                                              // 0 for the words of an absent array (staged as zeros), else 1
+        static_for<WJ>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const int e = c + GL * j;
+            const bool ok = c < GL && e < wtot;
+            const int ee = ok ? e : 0;
+            const int q = ee / WREC, w = ee - q * WREC;
+            const int64_t o = bN + (int64_t)q * S;              // first step of segment q
+            const T *ptr = p.K + bN * NU * NX;                 // absent arrays: a valid word, stride 0, masked to zero
+            int st = 0;
+            bool present = true;
+            if (w < NU * NX) { ptr = p.K + o * NU * NX + w; st = NU * NX; }
+            else if (w < NU * NX + NU) { ptr = p.k + o * NU + (w - NU * NX); st = NU; }
+            else if (w < NU * NX + NU + NX) { if (has_xh) { ptr = p.xhat + o * NX + (w - NU * NX - NU); st = NX; } else present = false; }
+            else if (has_uh) { ptr = p.uhat + o * NU + (w - NU * NX - NU - NX); st = NU; }
+            else present = false;
+            wp[j] = ptr; wst[j] = st;
+            wm[j] = present ? T(1) : T(0);
+            wmax[j] = N - 1 - q * S;                           // last iteration whose step is inside the horizon
+            wdst[j] = ok ? e : wtot;                           // surplus lanes / elements: dump word
+        });
+#ifdef ISLS_DIAG
+        twplan_ = __builtin_readcyclecounter();
+#endif
+        T wr[WD][WJ];
 #pragma unroll
-            for (int j = 0; j < NU * NX; ++j) Kt[j] = Kp[j];
+        for (int d = 0; d < WD; ++d) {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) kt[j] = kp[j];
+            for (int j = 0; j < WJ; ++j) wr[d][j] = wp[j][(int64_t)(d < wmax[j] ? d : wmax[j]) * wst[j]];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const T *wrec = wbuf + cs * WREC;
+        T *xo = p.x_out + (bN + t0) * NX, *uo = p.u_out + (bN + t0) * NU;     // direct stores when the stage does not fit
+        const int uoff = p.fa_zx ? N * NX : 0;
+        for (int i0 = 0; i0 < S; i0 += WD) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) xh[j] = xhp ? xhp[j] : T(0);
+            for (int d = 0; d < WD; ++d) {
+                const int i = i0 + d, t = t0 + i;
 #pragma unroll
-            for (int j = 0; j < NU; ++j) uh[j] = uhp ? uhp[j] : T(0);
-            T u[NU];
+                for (int j = 0; j < WJ; ++j) wbuf[wdst[j]] = wm[j] * wr[d][j];
+                slot_sync();
 #pragma unroll
-            for (int r = 0; r < NU; ++r) {
-                T acc = T(0);
+                for (int j = 0; j < WJ; ++j) wr[d][j] = wp[j][(int64_t)(i + WD < wmax[j] ? i + WD : wmax[j]) * wst[j]];
+                if (wlane && i < S && t < t1) {
+                    T u[NU], xh[NX], uh[NU];                   // unconditional reads: a select per word became a branch per word
 #pragma unroll
-                for (int j = 0; j < NX; ++j) acc += (xw[j] - (has_xh ? xh[j] : T(0))) * Kt[r * NX + j];
-                u[r] = (acc + alpha_w * kt[r]) + (has_uh ? uh[r] : T(0));
-            }
+                    for (int j = 0; j < NX; ++j) xh[j] = wrec[NU * NX + NU + j];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) xo[j] = accept ? xw[j] : xh[j];
+                    for (int r = 0; r < NU; ++r) uh[r] = wrec[NU * NX + NU + NX + r];
 #pragma unroll
-            for (int r = 0; r < NU; ++r) uo[r] = accept ? u[r] : uh[r];
-            if (p.fa_on) {                                     // hand x_t, u_t to the fused ADMM sweep through the (now dead)
-                const int uoff = p.fa_zx ? N * NX : 0;         // checkpoint area: [N][NX] (if constrained) then [N][NU]
-                if (p.fa_zx) {
+                    for (int r = 0; r < NU; ++r) {
+                        T acc = T(0);
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) ck[t * NX + j] = xw[j];
+                        for (int j = 0; j < NX; ++j) acc += (xw[j] - xh[j]) * wrec[r * NX + j];
+                        u[r] = (acc + alpha_w * wrec[NU * NX + r]) + uh[r];
+                    }
+                    // x_t, u_t go to the stage in LDS: a global store in this divergent block would make the wait for the
+                    // prefetched operands conservative (it then also waits for the previous iteration's write acknowledgements)
+                    if (stage_on) {
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) stage[t * NX + j] = xw[j];
+#pragma unroll
+                        for (int r = 0; r < NU; ++r) stage[N * NX + t * NU + r] = u[r];
+                    } else {                                   // long horizons: straight to HBM (and to the fused sweep's LDS area)
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) xo[i * NX + j] = accept ? xw[j] : wrec[NU * NX + NU + j];
+#pragma unroll
+                        for (int r = 0; r < NU; ++r) uo[i * NU + r] = accept ? u[r] : wrec[NU * NX + NU + NX + r];
+                        if (p.fa_on && p.fa_zx) {
+#pragma unroll
+                            for (int j = 0; j < NX; ++j) ck[t * NX + j] = xw[j];
+                        }
+                        if (p.fa_on && p.fa_zu) {
+#pragma unroll
+                            for (int r = 0; r < NU; ++r) ck[uoff + t * NU + r] = u[r];
+                        }
+                    }
+                    T xn[NX];
+                    model.step(xw, u, xn);
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) xw[j] = xn[j];
                 }
-                if (p.fa_zu) {
-#pragma unroll
-                    for (int r = 0; r < NU; ++r) ck[uoff + t * NU + r] = u[r];
-                }
             }
-            T xn[NX];
-            model.step(xw, u, xn);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) xw[j] = xn[j];
-            Kp += NU * NX; kp += NU; xo += NX; uo += NU;
-            if (xhp) xhp += NX;
-            if (uhp) uhp += NU;
         }
     }
+#ifdef ISLS_DIAG
+    const unsigned long long twloop_ = __builtin_readcyclecounter();
+#endif
+    // the winner's trajectory (or the kept nominal when the acceptance test failed: isls.py:365-369) leaves in one coalesced sweep
+    slot_sync();
+    if (stage_on && valid && c < GL) {
+        T *xo = p.x_out + bN * NX, *uo = p.u_out + bN * NU;
+        if (accept) {
+            for (int e = c; e < N * NX; e += GL) xo[e] = stage[e];
+            for (int e = c; e < N * NU; e += GL) uo[e] = stage[N * NX + e];
+        } else {
+            for (int e = c; e < N * NX; e += GL) xo[e] = p.xhat[bN * NX + e];
+            for (int e = c; e < N * NU; e += GL) uo[e] = p.uhat[bN * NU + e];
+        }
+    }
+#ifdef ISLS_DIAG
+    const unsigned long long twinner_ = __builtin_readcyclecounter();
+#endif
     if (p.fa_on) {
         // Fused ADMM update (isls_admm_update semantics, admm.py:43-85): the slot's lanes sweep the flat [N*d] blocks,
         // x / u from LDS, z / lambda / bounds coalesced from HBM -- independent iterations, no per-step round trip.
@@ -478,26 +597,48 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
             T *zz = isx ? p.fa_zx : p.fa_zu, *ll = isx ? p.fa_lx : p.fa_lu;
             if (zz == nullptr) continue;                       // uniform
             const int d = isx ? NX : NU, cnt = N * d, proj = isx ? p.fa_proj_x : p.fa_proj_u;
-            const T *src = isx ? ck : ck + (p.fa_zx ? N * NX : 0);
+            const T *src = stage_on ? (isx ? stage : stage + N * NX) : (isx ? ck : ck + (p.fa_zx ? N * NX : 0));
             const View<T> &lo = isx ? p.fa_xlo : p.fa_ulo, &hi = isx ? p.fa_xhi : p.fa_uhi;
             T p2 = T(0), d2 = T(0);
             if (valid && c < GL) {
                 const int64_t o = bN * d;
-                for (int e = c; e < cnt; e += GL) {
-                    const T xv = src[e], zp = zz[o + e], lv = ll[o + e];
-                    const T arg = (p.fa_relax * xv + (T(1) - p.fa_relax) * zp) + lv;
-                    T zn = arg;
-                    if (proj == ISLS_PROJ_BOX) {
-                        const int t = e / d, i = e - t * d;
-                        const T lo_v = lo.at(b, t)[i], hi_v = hi.at(b, t)[i];
-                        zn = arg < lo_v ? lo_v : arg;
-                        zn = zn > hi_v ? hi_v : zn;
+                // chunks of SW elements per lane: all loads of a chunk are issued before its first store, so a lane pays one
+                // HBM round trip per chunk instead of one per element (the stores to z / lambda kept the compiler from
+                // hoisting the next element's loads)
+                constexpr int SW = ISLS_RO_SW;
+                for (int e0 = c; e0 < cnt; e0 += GL * SW) {
+                    T zp[SW], lv[SW], lo_v[SW], hi_v[SW];
+#pragma unroll
+                    for (int q = 0; q < SW; ++q) {
+                        const int e = e0 + GL * q < cnt ? e0 + GL * q : cnt - 1;      // clamped (surplus results are dropped)
+                        zp[q] = zz[o + e];
+                        lv[q] = ll[o + e];
+                        if (proj == ISLS_PROJ_BOX) {
+                            const int t = e / d, i = e - t * d;
+                            lo_v[q] = lo.at(b, t)[i];
+                            hi_v[q] = hi.at(b, t)[i];
+                        } else {
+                            lo_v[q] = hi_v[q] = T(0);
+                        }
                     }
-                    const T rr = xv - zn;
-                    ll[o + e] = lv + rr;
-                    zz[o + e] = zn;
-                    p2 += rr * rr;
-                    d2 += (zn - zp) * (zn - zp);
+#pragma unroll
+                    for (int q = 0; q < SW; ++q) {
+                        const int e = e0 + GL * q;
+                        if (e < cnt) {
+                            const T xv = src[e];
+                            const T arg = (p.fa_relax * xv + (T(1) - p.fa_relax) * zp[q]) + lv[q];
+                            T zn = arg;
+                            if (proj == ISLS_PROJ_BOX) {
+                                zn = arg < lo_v[q] ? lo_v[q] : arg;
+                                zn = zn > hi_v[q] ? hi_v[q] : zn;
+                            }
+                            const T rr = xv - zn;
+                            ll[o + e] = lv[q] + rr;
+                            zz[o + e] = zn;
+                            p2 += rr * rr;
+                            d2 += (zn - zp[q]) * (zn - zp[q]);
+                        }
+                    }
                 }
             }
             if (c < GL) { c_aug[c] = p2; c_pln[c] = d2; }
@@ -528,8 +669,9 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
     }
 #ifdef ISLS_DIAG
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
-        printf("ro diag block %d: put+sync %llu fetch %llu u %llu cost %llu model %llu | search %llu winner %llu cycles (N=%d nseg=%d)\n",
-               blockIdx.x, racc[0], racc[1], racc[2], racc[3], racc[4], tsearch_ - tstart_, __builtin_readcyclecounter() - tsearch_, N, NSEG);
+        printf("ro diag block %d: put+sync %llu fetch %llu u %llu cost %llu model %llu | search %llu argmin %llu winner %llu (plan done %llu, loop done %llu) sweep %llu cycles (N=%d nseg=%d)\n",
+               blockIdx.x, racc[0], racc[1], racc[2], racc[3], racc[4], tsearch_ - tstart_, targmin_ - tsearch_, twinner_ - targmin_, twplan_ - targmin_, twloop_ - targmin_,
+               __builtin_readcyclecounter() - twinner_, N, NSEG);
 #endif
 }
 
@@ -567,14 +709,20 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_ar
     // winner replay geometry: NSEG segments of S steps, NSEG <= lanes of a slot
     int nseg = GL < kMaxSeg ? GL : kMaxSeg;
     if (nseg > a.N) nseg = a.N;
+    bool stage_on = true;
     auto smem_bytes = [&](int ns) {
-        const int slot = (a.n == 6 ? RoLayout<6, 3>::slot_elems(a.L, GL, ns) : a.n == 2 ? RoLayout<2, 1>::slot_elems(a.L, GL, ns)
-                          : a.n == 4 ? RoLayout<4, 2>::slot_elems(a.L, GL, ns) : RoLayout<9, 3>::slot_elems(a.L, GL, ns));
+        const int slot = (a.n == 6 ? RoLayout<6, 3>::slot_elems(a.L, GL, ns, a.N, stage_on) : a.n == 2 ? RoLayout<2, 1>::slot_elems(a.L, GL, ns, a.N, stage_on)
+                          : a.n == 4 ? RoLayout<4, 2>::slot_elems(a.L, GL, ns, a.N, stage_on) : RoLayout<9, 3>::slot_elems(a.L, GL, ns, a.N, stage_on));
         return (size_t)TPW * slot * sizeof(T);
     };
-    while (nseg > 1 && smem_bytes(nseg) > 20 * 1024) --nseg;   // <= 20 KB per wavefront keeps 8 workgroups per CU
+    // the winner's trajectory is collected in LDS when that keeps the workgroup under 28 KB (>= 5 per CU); longer horizons
+    // store it step by step
+    if (smem_bytes(1) > 28 * 1024) stage_on = false;
+    while (nseg > 1 && smem_bytes(nseg) > 26 * 1024 + 512) --nseg;   // <= 26.5 KB per wavefront keeps 6 workgroups per CU
+    while (nseg > 1 && nseg * (a.m * a.n + 2 * a.m + a.n) > 8 * GL) --nseg;    // winner staging: <= 8 words per lane and iteration
     p.seg_len = (a.N + nseg - 1) / nseg;
     p.nseg = (a.N + p.seg_len - 1) / p.seg_len;                // drop empty trailing segments
+    p.stage_on = stage_on ? 1 : 0;
     p.fa_on = 0;
     p.fa_zx = p.fa_lx = p.fa_zu = p.fa_lu = p.fa_res = p.fa_res_prev = nullptr;
     p.fa_active = p.fa_iters = nullptr;
@@ -582,8 +730,8 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_ar
     p.fa_relax = p.fa_tol_abs = p.fa_tol_rel = T(0);
     const size_t smem = smem_bytes(p.nseg);
     if (smem > 64 * 1024) return ISLS_ERR_UNSUPPORTED;
-    // the fused ADMM sweep takes x_t, u_t through the checkpoint area of the slot: [N][n] + [N][m] words must fit
-    if (fused && (int64_t)a.N * ((fused->zx ? a.n : 0) + (fused->zu ? a.m : 0)) > (int64_t)(a.L + 1) * p.nseg * a.n) fused = nullptr;
+    // without the stage the fused ADMM sweep takes x_t, u_t through the checkpoint area: [N][n] + [N][m] words must fit
+    if (fused && !stage_on && (int64_t)a.N * ((fused->zx ? a.n : 0) + (fused->zu ? a.m : 0)) > (int64_t)(a.L + 1) * p.nseg * a.n) fused = nullptr;
     if (fused) {                                               // validated by the caller (rollout_can_fuse_admm)
         if (did_fuse) *did_fuse = true;
         const isls_admm_args &f = *fused;
