@@ -303,12 +303,22 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
         // padded with dead steps (t >= N: loads clamped, nothing accumulated or stored), so the body exists once,
         // stays free of closures (a step lambda keeps its captures in scratch memory, and a scratch access per
         // step drains the ring with s_waitcnt vmcnt(0)) and every VMEM instruction of the loop is unconditional.
+        // running source pointers: the fetches walk t = 0, 1, 2, ... (each ring entry is refilled D steps ahead), so a
+        // pointer advances by its stride after every fetch until it sits on step N-1 (the padding fetches repeat that step);
+        // one 64-bit multiply-add per pointer instead of rebuilding base + t * stride for every load
         T ra[D][JM], rb[D][JM];
+        const T *ca[JM], *cb[JM];
+#pragma unroll
+        for (int j = 0; j < JM; ++j) { ca[j] = pa[j]; cb[j] = pb[j]; }
+        int tf = 0;                                            // step the pointers sit on
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int64_t tt = d < N ? d : N - 1;
 #pragma unroll
-            for (int j = 0; j < JM; ++j) { ra[d][j] = pa[j][tt * stp[j]]; rb[d][j] = pb[j][tt * stp[j]]; }
+            for (int j = 0; j < JM; ++j) { ra[d][j] = *ca[j]; rb[d][j] = *cb[j]; }
+            const int adv = tf < N - 1 ? 1 : 0;
+            tf += adv;
+#pragma unroll
+            for (int j = 0; j < JM; ++j) { ca[j] += adv * stp[j]; cb[j] += adv * stp[j]; }
             __builtin_amdgcn_sched_barrier(0);                  // keep the issue order = consumption order (vmcnt is in-order)
         }
         T *ckc = ck + (c < L ? c : L) * NSEG * NX;             // this candidate's checkpoints (row L = dump)
@@ -325,10 +335,13 @@ __global__ __launch_bounds__(64, (rollout_occupancy<NX, GLMIN>())) void rollout_
                     rec[dst[j]] = ma[j] * fma(-mb[j], rb[d][j], ra[d][j]);
                 slot_sync();                                   // record(t) visible to the slot
                 RSTAMP(0)
-                {
-                    const int64_t tn = t + D < N ? t + D : N - 1;   // refill this ring entry (clamped, unconditional)
+                {                                              // refill this ring entry: step min(t + D, N-1), unconditional
 #pragma unroll
-                    for (int j = 0; j < JM; ++j) { ra[d][j] = pa[j][tn * stp[j]]; rb[d][j] = pb[j][tn * stp[j]]; }
+                    for (int j = 0; j < JM; ++j) { ra[d][j] = *ca[j]; rb[d][j] = *cb[j]; }
+                    const int adv = tf < N - 1 ? 1 : 0;
+                    tf += adv;
+#pragma unroll
+                    for (int j = 0; j < JM; ++j) { ca[j] += adv * stp[j]; cb[j] += adv * stp[j]; }
                 }
                 RSTAMP(1)
                 if (t == next_ck && live) {                    // uniform: state of every candidate at a segment start
