@@ -17,6 +17,7 @@ try:  # torch is plumbing (device memory, streams); the binding itself works on 
 except Exception:  # pragma: no cover
     torch = None
 
+ABI_VERSION = 101            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
@@ -193,6 +194,10 @@ def load_hip_library(path=None):
         raise IslsError(f"{path} not found: build it with `python __graft_entry__.py` "
                         f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(path)
+    lib.isls_version.restype = C.c_int
+    if lib.isls_version() != ABI_VERSION:                      # a stale build would read the argument blocks with another layout
+        raise IslsError(f"{path} reports ABI version {lib.isls_version()}, this binding is for {ABI_VERSION}: rebuild it "
+                        f"(`python __graft_entry__.py`)")
     lib.isls_error_string.restype = C.c_char_p
     lib.isls_timing_read_ms.restype = C.c_double
     lib.isls_timing_read_ms.argtypes = [C.c_int, C.POINTER(C.c_int)]

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ISLS_VERSION 100
+#define ISLS_VERSION 101   /* 101: isls_gain_args.rec / isls_ff_args.rec, isls_columns_*, isls_dense_closed_loop_* */
 
 #define ISLS_OK 0
 #define ISLS_ERR_ARG (-1)
