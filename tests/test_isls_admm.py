@@ -94,13 +94,24 @@ def test_transfer_matrices_reproduce_rollout(oracle):
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 1e-4)])
-@pytest.mark.parametrize("n,m", [(6, 3), (4, 2), (9, 3), (2, 1)])
-def test_columns_rollout_kernel(n, m, dtype, tol):
+@pytest.mark.parametrize("n,m,C", [(6, 3, 4), (6, 3, 2), (4, 2, 3), (9, 3, 4), (9, 3, 2), (2, 1, 3), (2, 1, 2)])
+def test_columns_rollout_kernel(n, m, C, dtype, tol):
+    _check_columns_rollout(n, m, C, 12, dtype, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [2, 3, 5, 9])
+def test_columns_rollout_short_horizons(N):
+    """horizons shorter than / not a multiple of the prefetch ring (padded dead steps, clamped fetches)"""
+    _check_columns_rollout(6, 3, 4, N, np.float64, 1e-10)
+
+
+def _check_columns_rollout(n, m, C, N, dtype, tol):
     import torch
     from isls.engine import kernels
     from oracle.isls_admm_dense import transfer_matrices
     rng = np.random.default_rng(n * 10 + m)
-    B, N, C = 5, 12, min(n, 3) + 1
+    B = 5
     A = (np.eye(n) + 0.1 * rng.standard_normal((B, N, n, n))).astype(dtype)
     Bm = (0.3 * rng.standard_normal((B, N, n, m))).astype(dtype)
     K = (0.2 * rng.standard_normal((B, N, m, n))).astype(dtype)
