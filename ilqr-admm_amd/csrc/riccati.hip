@@ -186,6 +186,9 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
             }
         }
         const int64_t o = bN + t;
+        // packed records are blocked by wavefront, [block][t][slot][RW]: the TPW trajectories of a workgroup write (and the
+        // feed-forward pass reads) one contiguous burst per step
+        const int64_t orec = ((int64_t)blockIdx.x * N + t) * TPW + s;
 #pragma unroll
         for (int r = 0; r < NU; ++r) rec[kdst + r * kstr] = Kc[r];
         if (xl && valid) {
@@ -215,13 +218,13 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                         v = (i == r) ? vr : v;
                     }
                     p.fac[(o * NU + i) * NU + c] = v;
-                    if (p.rec) p.rec[o * RW + RFAC + i * NU + c] = v;
+                    if (p.rec) p.rec[orec * RW + RFAC + i * NU + c] = v;
                 }
             }
             // packed record of the feed-forward pass (riccati_ffrec.hip): closed-loop matrix Phi = A + B K (lane i owns
             // column i, like its column of K), then B, K as they are
             if (p.rec) {
-                T *ro = p.rec + o * RW;
+                T *ro = p.rec + orec * RW;
                 if (xl) {
 #pragma unroll
                     for (int k = 0; k < NX; ++k) {

@@ -175,7 +175,7 @@ class OuterArgs(C.Structure):
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
-           ["isls_ff_segments", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_pause",
+           ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_pause",
             "isls_timing_read_ms"]
 
 
@@ -244,6 +244,22 @@ def _dense(x, shape, name):
     if not contiguous:
         raise ValueError(f"{name}: must be C-contiguous")
     return x
+
+
+def ff_record_elems(B, N, n, m):
+    """isls_ff_record_elems: elements of the packed-record buffer of the gain pass (blocked by wavefront)."""
+    tpw = 64 // (n + m)
+    return -(-B // tpw) * tpw * N * (n * n + 2 * n * m + m * m)
+
+
+def _record(rec, B, N, n, m):
+    if rec is None:
+        return None
+    size = rec.numel() if _is_torch(rec) else rec.size
+    contiguous = rec.is_contiguous() if _is_torch(rec) else rec.flags["C_CONTIGUOUS"]
+    if size < ff_record_elems(B, N, n, m) or not contiguous:
+        raise ValueError(f"rec: needs a contiguous buffer of {ff_record_elems(B, N, n, m)} elements")
+    return rec
 
 
 def make_view(x, B, N, core, name):
@@ -318,7 +334,7 @@ class Kernels:
         a.K, a.Quu = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(Quu, (B, N, m, m), "Quu"))
         a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
         a.status, a.active = _ptr(status), _ptr(active)
-        a.rec = _ptr(_dense(rec, (B, N, n * n + 2 * n * m + m * m), "rec"))
+        a.rec = _ptr(_record(rec, B, N, n, m))
         return a
 
     @staticmethod
@@ -342,7 +358,7 @@ class Kernels:
         a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
         a.k = _ptr(_dense(k, (B, N, m), "k"))
         a.active = _ptr(active)
-        a.rec = _ptr(_dense(rec, (B, N, n * n + 2 * n * m + m * m), "rec"))
+        a.rec = _ptr(_record(rec, B, N, n, m))
         return a
 
     @staticmethod

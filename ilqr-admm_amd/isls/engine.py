@@ -253,8 +253,7 @@ class Engine:
         if os.environ.get("ISLS_FF_RECORD", "1") == "0":
             return None
         if getattr(self, "_ffrec", None) is None:
-            n, m = self.n, self.m
-            self._ffrec = torch.zeros(self.B, self.N, n * n + 2 * n * m + m * m, dtype=self.dtype, device=self.device)
+            self._ffrec = torch.zeros(capi.ff_record_elems(self.B, self.N, self.n, self.m), dtype=self.dtype, device=self.device)
         return self._ffrec
 
     def gain(self, active=None, rec=None):

@@ -108,9 +108,15 @@ typedef struct isls_gain_args {
     void *K, *Quu, *fac, *Qux;
     int32_t *status;       /* [B] OR-ed in */
     const int32_t *active; /* nullable */
-    void *rec;             /* nullable: [B,N,n*n+2*n*m+m*m] packed step records [A+B K | B | K | fac] (row-major blocks)
-                            * for the feed-forward pass (isls_ff_args.rec); rows t = N-1 are not written          */
+    void *rec;             /* nullable: packed step records [A+B K | B | K | fac] (row-major blocks, RW = n*n+2*n*m+m*m words)
+                            * for the feed-forward pass (isls_ff_args.rec).  Opaque to the caller: an allocation of
+                            * isls_ff_record_elems(B,N,n,m) elements, laid out [ceil(B/T)][N][T][RW] with T = 64/(n+m)
+                            * trajectories per wavefront, so that a wavefront streams one contiguous burst per step;
+                            * steps t = N-1 are not written                                                        */
 } isls_gain_args;
+
+/* elements of the packed-record buffer (see isls_gain_args.rec) */
+int64_t isls_ff_record_elems(int32_t B, int32_t N, int32_t n, int32_t m);
 
 int isls_riccati_gain_f64(const isls_gain_args *a, void *stream);
 int isls_riccati_gain_f32(const isls_gain_args *a, void *stream);

@@ -52,9 +52,10 @@ class DualKernels:
             dkw = dict(dkw, seg=self._prepare_segments(dargs, dkw))
         if self.ff_record and name == "riccati_gain":
             B, N, m, n = dargs[4].shape
-            self._rec = torch.full((B, N, n * n + 2 * n * m + m * m), float("nan"), dtype=dargs[4].dtype, device="cuda")
+            self._rec = torch.full((capi.ff_record_elems(B, N, n, m),), float("nan"), dtype=dargs[4].dtype, device="cuda")
+            self._rec_dims = (B, N)
             dkw = dict(dkw, rec=self._rec)
-        if self.ff_record and name == "riccati_ff" and self._rec is not None and self._rec.shape[:2] == dargs[4].shape[:2]:
+        if self.ff_record and name == "riccati_ff" and self._rec is not None and self._rec_dims == tuple(dargs[4].shape[:2]):
             dkw = dict(dkw, rec=self._rec)
         for blk in ("x", "u"):                                 # set descriptors hold pointers: rebuild them on the device
             if dkw.get(blk + "_sets") is not None:
