@@ -1,15 +1,16 @@
-"""Batched `iSLS.isls_admm` (isls/isls.py:503-712): iterative SLS with feedback columns [d, phi] and ADMM on their rows.
+"""Feedback columns [d, phi] in DP form: batched `iSLS.isls_admm` (isls/isls.py:503-712) and the state-constrained route of
+`SLS.ADMM_SLS` (isls/sls.py:319-454).
 
-The reference solves, per outer iteration, one dense (N m)^2 system for the 1 + dim columns and multiplies by the dense
-transfer matrices.  Here every column is the minimiser of a time-varying LQ problem about the nominal (see
-`isls_columns_args` in include/isls_hip.h), so the x-step of an ADMM iteration is
+The reference solves one dense (N m)^2 system for the 1 + dim columns per x-step and multiplies by the dense transfer
+matrices.  Here every column is the minimiser of a time-varying LQ problem about the nominal (see `isls_columns_args` in
+include/isls_hip.h), so the x-step of an ADMM iteration is
 
-    C feed-forward passes (isls_riccati_ff)  ->  isls_columns_rollout  ->  open-loop line search on column 0 (isls_rollout_ls
-    with zero gains: `rollout_batch(x_nom, u_nom + alpha d_u)`, isls.py:593-606)
+    C feed-forward passes (isls_riccati_ff)  ->  isls_columns_rollout   [-> open-loop line search on column 0, isls_admm only:
+    isls_rollout_ls with zero gains = `rollout_batch(x_nom, u_nom + alpha d_u)`, isls.py:593-606]
 
-after ONE Riccati gain pass per outer iteration, and the z-step is isls_columns_admm around the row projection
-(isls_project_rows for `projections.ConvexSets`, the caller's numpy function otherwise).  Results equal the dense form up to
-rounding, including the last control (SURVEY 8a quirk i), which the dense form sets from its own cost term.
+after ONE Riccati gain pass, and the z-step is isls_columns_admm around the row projection (isls_project_rows for
+`projections.ConvexSets`, the caller's numpy function otherwise).  Results equal the dense form up to rounding, including
+the last control (SURVEY 8a quirk i), which the dense form sets from its own cost term.
 """
 import numpy as np
 import torch
@@ -19,18 +20,125 @@ from .engine import _stream_ptr
 from .projections import ConvexSets
 
 
-def _row_projection(project, d, C):
-    """project_x / project_u of isls_admm -> None, ConvexSets on rows of dimension C (device) or a callable (host)."""
+def _row_projection(project, C):
+    """project_x / project_u -> None, ConvexSets on rows of dimension C (device) or a callable (host)."""
     if project is False or project is None:
         return None
     if isinstance(project, ConvexSets):
         if project.dim != C or project.cols != (0, C):
-            raise ValueError(f"isls_admm projects rows [d, phi] of dimension {C}; the ConvexSets acts on "
+            raise ValueError(f"the projection acts on rows [d, phi] of dimension {C}; this ConvexSets acts on "
                              f"columns {project.cols} of rows of dimension {project.dim}")
         return project
     if callable(project):
         return project
-    raise TypeError("project_x / project_u must be False, a projections.ConvexSets or a callable (rows, nominal) -> rows")
+    raise TypeError("project_x / project_u must be False, a projections.ConvexSets or a callable on the rows")
+
+
+class ColumnSolver:
+    """Device state and steps of the ADMM over the feedback columns of one engine (gain pass once, then x-steps and z-steps)."""
+
+    def __init__(self, engine, C, project_x, project_u, nominal_in_projection):
+        e = self.e = engine
+        self.C, self.nominal_in_projection = int(C), nominal_in_projection
+        B, N, n, m = e.B, e.N, e.n, e.m
+        z = lambda *s: torch.zeros(*s, dtype=e.dtype, device=e.device)        # noqa: E731
+        self.kcol, self.dx, self.du = z(C, B, N, m), z(C, B, N, n), z(C, B, N, m)
+        self.zero_x, self.zero_u = z(1, 1, n), z(1, 1, m)
+        self.blocks = {}
+        for key, proj, d in (("x", _row_projection(project_x, C), n), ("u", _row_projection(project_u, C), m)):
+            if proj is None:
+                self.blocks[key] = None
+                continue
+            blk = dict(xx=self.dx if key == "x" else self.du, z=z(C, B, N, d), l=z(C, B, N, d), z_prev=z(C, B, N, d),
+                       work=z(B, N * d, C), proj=proj, desc=None)
+            if isinstance(proj, ConvexSets):
+                sets = [{k_: (e._t(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k_, v in st.items()}
+                        for st in proj.sets]
+                blk["desc"] = capi.Kernels.project_args(blk["work"], blk["work"], sets, rho=proj.rho, max_iter=proj.max_iter,
+                                                        threshold=proj.threshold, active=e.admm_active)
+            self.blocks[key] = blk
+        self.constrained = self.blocks["x"] is not None or self.blocks["u"] is not None
+
+    def prepare(self, active):
+        """gain pass (+ packed records, + operators of the time-parallel feed-forward passes) for the current expansion"""
+        e = self.e
+        for key, W in (("x", e.Qr), ("u", e.Rr)):                              # residual weights of the projected blocks
+            if self.blocks[key] is not None:
+                if W is None:
+                    raise ValueError(f"project_{key} needs rho_{key}")
+                self.blocks[key]["W"] = W
+        self.rec = e.ff_record()
+        e.gain(active=active, rec=self.rec)
+        self.seg = e.ff_seg()
+        if self.seg is not None:
+            e.feedforward_prepare(self.seg, active=active)
+        self.Cuu = e.hessians()[1]
+
+    def restart(self, active):
+        """lmb <- 0, residual history <- 1e6, every active problem iterates (z keeps its value: warm start)"""
+        e = self.e
+        e.admm_active.copy_(active)
+        e.admm_iters.zero_()
+        e.res_prev.fill_(1e6)
+        for blk in self.blocks.values():
+            if blk is not None:
+                blk["l"].zero_()
+
+    def x_step(self):
+        """[d_x, phi_x], [d_u, phi_u] for the targets z - lmb: C feed-forward passes, then the column rollout.  A weight that
+        is set without a projected block pulls towards zero (its target is the zero vector), as in the reference, where
+        Qr / Rr enter the normal equations whether or not the block is projected (isls.py:568-573, sls.py:342-349)."""
+        e, bx, bu = self.e, self.blocks["x"], self.blocks["u"]
+        act = e.admm_active
+        if not hasattr(self, "_zero_zx"):
+            zz = lambda d: torch.zeros(e.B, e.N, d, dtype=e.dtype, device=e.device)       # noqa: E731
+            self._zero_zx, self._zero_zu = zz(e.n), zz(e.m)
+        for c in range(self.C):
+            zx, lx = (bx["z"][c], bx["l"][c]) if bx is not None else (self._zero_zx, self._zero_zx)
+            zu, lu = (bu["z"][c], bu["l"][c]) if bu is not None else (self._zero_zu, self._zero_zu)
+            e.kern.riccati_ff(e.A, e.Bm, e.c0x if c == 0 else self.zero_x, e.c0u if c == 0 else self.zero_u, e.K, e.Quu, e.fac,
+                              e.Qux, self.kcol[c], Qr=e.Qr, Rr=e.Rr, zx=zx if e.Qr is not None else None,
+                              lx=lx if e.Qr is not None else None, zu=zu if e.Rr is not None else None,
+                              lu=lu if e.Rr is not None else None, solve_mode=e.solve_mode, active=act, seg=self.seg, rec=self.rec,
+                              stream=_stream_ptr())
+        e.kern.columns_rollout(e.A, e.Bm, self.Cuu, e.c0u, e.K, self.kcol, self.dx, self.du,
+                               Rr=e.Rr if bu is not None else None, zu=bu["z"] if bu is not None else None,
+                               lu=bu["l"] if bu is not None else None, active=act, stream=_stream_ptr())
+
+    def z_step(self, relax, tol_abs, tol_rel, log_row=None):
+        """z = Proj(relax x + (1 - relax) z + lmb), lmb += x - z, rho-scaled residuals and the two stop rules"""
+        e, bx, bu = self.e, self.blocks["x"], self.blocks["u"]
+        act = e.admm_active
+        dims = (e.B, e.N, e.n, e.m, self.C)
+        noms = {"x": e.xhat, "u": e.uhat}
+        for key, blk in self.blocks.items():
+            if blk is not None:
+                blk["nom"] = noms[key] if (self.nominal_in_projection and blk["desc"] is not None) else None
+        e.kern.columns_admm(0, dims, e.res, e.res_prev, x=bx, u=bu, relax=relax, active=act, stream=_stream_ptr())
+        for key, blk in self.blocks.items():
+            if blk is None:
+                continue
+            if blk["desc"] is not None:
+                e.kern._call("project_rows", e.sfx, blk["desc"], _stream_ptr())
+            else:                                                               # the caller's numpy projection, problem by problem
+                rows, on_h = blk["work"].cpu().numpy(), act.cpu().numpy()
+                nom_h = noms[key].cpu().numpy() if self.nominal_in_projection else None
+                for b in range(e.B):
+                    if on_h[b]:
+                        arg = rows[b].astype(np.float64)
+                        out = blk["proj"](arg, nom_h[b]) if nom_h is not None else blk["proj"](arg)
+                        rows[b] = np.asarray(out, dtype=np.float64).reshape(rows[b].shape)
+                blk["work"].copy_(e._t(rows))
+        e.kern.columns_admm(1, dims, e.res, e.res_prev, x=bx, u=bu, relax=relax, tol_abs=tol_abs, tol_rel=tol_rel, active=act,
+                            iters=e.admm_iters, stream=_stream_ptr())
+        if log_row is not None:
+            log_row.copy_(e.res)
+
+    def columns(self):
+        """(x_x [B, N n, C], x_u [B, N m, C]) of the last x-step in the reference's row layout"""
+        e = self.e
+        return (self.dx.permute(1, 2, 3, 0).reshape(e.B, e.N * e.n, self.C).cpu().numpy().astype(np.float64),
+                self.du.permute(1, 2, 3, 0).reshape(e.B, e.N * e.m, self.C).cpu().numpy().astype(np.float64))
 
 
 def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=False, max_admm_iter=20, k_max=20,
@@ -46,89 +154,38 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     B, N, n, m, C = self.batch, self.N, self.x_dim, self.u_dim, int(dim) + 1
     if not 1 <= dim <= n or C > capi.MAX_ROW_DIM:
         raise ValueError(f"dim must be in [1, {min(n, capi.MAX_ROW_DIM - 1)}]")
-    px, pu = _row_projection(project_x, n, C), _row_projection(project_u, m, C)
+    cs = ColumnSolver(e, C, project_x, project_u, nominal_in_projection=True)
     free = (-np.inf, np.inf)
-    e.set_admm(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None,
-               x_box=free if px is not None else None, u_box=free if pu is not None else None, relax=alpha)
-    kern, sfx = e.kern, e.sfx
-    z = lambda *s: torch.zeros(*s, dtype=e.dtype, device=e.device)            # noqa: E731
-    kcol, dx, du = z(C, B, N, m), z(C, B, N, n), z(C, B, N, m)
-    zero_x, zero_u, zero_K = z(1, 1, n), z(1, 1, m), z(B, N, m, n)
-    blocks = {}
-    for key, proj, d, W, nom in (("x", px, n, e.Qr, e.xhat), ("u", pu, m, e.Rr, e.uhat)):
-        if proj is None:
-            blocks[key] = None
-            continue
-        blk = dict(xx=dx if key == "x" else du, z=z(C, B, N, d), l=z(C, B, N, d), z_prev=z(C, B, N, d),
-                   work=z(B, N * d, C), W=W, nom=nom if isinstance(proj, ConvexSets) else None, proj=proj, desc=None)
-        if isinstance(proj, ConvexSets):
-            sets = [{k_: (e._t(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k_, v in st.items()}
-                    for st in proj.sets]
-            blk["desc"] = capi.Kernels.project_args(blk["work"], blk["work"], sets, rho=proj.rho, max_iter=proj.max_iter,
-                                                    threshold=proj.threshold, active=e.admm_active)
-        blocks[key] = blk
-    bx, bu = blocks["x"], blocks["u"]
-    constrained = bx is not None or bu is not None
-    J = int(max_admm_iter) if constrained else 1
+    e.set_admm(rho_x=rho_x if cs.blocks["x"] is not None else None, rho_u=rho_u if cs.blocks["u"] is not None else None,
+               x_box=free if cs.blocks["x"] is not None else None, u_box=free if cs.blocks["u"] is not None else None, relax=alpha)
+    dx, du = cs.dx, cs.du
+    zero_K = torch.zeros(B, N, m, n, dtype=e.dtype, device=e.device)
+    J = int(max_admm_iter) if cs.constrained else 1
     L = int(max_line_search)
-    logbuf = z(J, B, 2)
+    logbuf = torch.zeros(J, B, 2, dtype=e.dtype, device=e.device)
     e.outer_active.fill_(1)
     hist = [[float(c)] for c in np.atleast_1d(np.asarray(self.cost, dtype=np.float64))]
     mask3 = lambda a: a.to(torch.bool).view(B, 1, 1)                          # noqa: E731
     for k in range(k_max):
         self._linearize(get_AB)
         e.expand()
-        rec = e.ff_record()                                                     # packed step records for the C x J ff passes
-        e.gain(active=e.outer_active, rec=rec)
-        seg = e.ff_seg()                                                        # time-parallel feed-forward passes (isls_ffseg)
-        if seg is not None:
-            e.feedforward_prepare(seg, active=e.outer_active)
-        Cuu = e.hessians()[1]
-        e.admm_active.copy_(e.outer_active)
-        e.admm_iters.zero_()
-        e.res_prev.fill_(1e6)
-        for blk in (bx, bu):
-            if blk is not None:
-                blk["l"].zero_()                                                # lmb restarts, z is warm-started (isls.py:613-616)
+        cs.prepare(e.outer_active)
+        cs.restart(e.outer_active)                                              # lmb restarts, z is warm-started (isls.py:613-616)
         for j in range(J):
             act = e.admm_active
-            for c in range(C):                                                  # STEP 1: the columns' feed-forward terms
-                kern.riccati_ff(e.A, e.Bm, e.c0x if c == 0 else zero_x, e.c0u if c == 0 else zero_u, e.K, e.Quu, e.fac,
-                                e.Qux, kcol[c], Qr=e.Qr if bx is not None else None, Rr=e.Rr if bu is not None else None,
-                                zx=bx["z"][c] if bx is not None else None, lx=bx["l"][c] if bx is not None else None,
-                                zu=bu["z"][c] if bu is not None else None, lu=bu["l"][c] if bu is not None else None,
-                                solve_mode=e.solve_mode, active=act, seg=seg, rec=rec, stream=_stream_ptr())
-            kern.columns_rollout(e.A, e.Bm, Cuu, e.c0u, e.K, kcol, dx, du, Rr=e.Rr if bu is not None else None,
-                                 zu=bu["z"] if bu is not None else None, lu=bu["l"] if bu is not None else None,
-                                 active=act, stream=_stream_ptr())
+            cs.x_step()
             # line search on d_u: open-loop rollouts of u_nom + alpha d_u, plain cost, first arg-min (isls.py:593-606)
-            kern.rollout_ls(e.model, e.model_par, zero_K, du[0], e.xhat, e.uhat, e.alphas[:L], e.Qtab, e.ztab, e.seq, e.u_std,
-                            e.xx, e.xu, best=e.best, cost_new=e.cost_new, flags=0, status=e.status, active=act,
-                            q_nonzero=e.q_nonzero, cost_model=e.cost_model, cost_par=e.cost_par, stream=_stream_ptr())
+            e.kern.rollout_ls(e.model, e.model_par, zero_K, du[0], e.xhat, e.uhat, e.alphas[:L], e.Qtab, e.ztab, e.seq, e.u_std,
+                              e.xx, e.xu, best=e.best, cost_new=e.cost_new, flags=0, status=e.status, active=act,
+                              q_nonzero=e.q_nonzero, cost_model=e.cost_model, cost_par=e.cost_par, stream=_stream_ptr())
             on = mask3(act)
             step = torch.where(act.to(torch.bool), e.alphas[:L][e.best.long()], torch.ones_like(e.cost_new))
             du[0].mul_(step.view(B, 1, 1))                                      # du_opt[:, 0] = alpha* d_u
             dx[0].copy_(torch.where(on, e.xx - e.xhat, dx[0]))                  # dx_opt[:, 0] = x_noms[ind] - x_nom
-            if not constrained:
+            if not cs.constrained:
                 e.admm_iters.add_(act)
                 break
-            # STEP 2: z = Proj(alpha x + (1 - alpha) z + lmb), lmb += x - z, residuals and stop rules (isls.py:626-665)
-            dims = (B, N, n, m, C)
-            kern.columns_admm(0, dims, e.res, e.res_prev, x=bx, u=bu, relax=alpha, active=act, stream=_stream_ptr())
-            for blk, nom in ((bx, e.xhat), (bu, e.uhat)):
-                if blk is None:
-                    continue
-                if blk["desc"] is not None:
-                    kern._call("project_rows", sfx, blk["desc"], _stream_ptr())
-                else:                                                           # the caller's numpy projection, problem by problem
-                    rows, nom_h, on_h = blk["work"].cpu().numpy(), nom.cpu().numpy(), act.cpu().numpy()
-                    for b in range(B):
-                        if on_h[b]:
-                            rows[b] = np.asarray(blk["proj"](rows[b].copy(), nom_h[b]), dtype=np.float64)
-                    blk["work"].copy_(e._t(rows))
-            kern.columns_admm(1, dims, e.res, e.res_prev, x=bx, u=bu, relax=alpha, tol_abs=threshold, tol_rel=1e-3,
-                              active=act, iters=e.admm_iters, stream=_stream_ptr())
-            logbuf[j].copy_(e.res)
+            cs.z_step(alpha, threshold, 1e-3, log_row=logbuf[j])                # isls.py:626-665
             if not bool(act.any().item()):
                 break
         # new nominal: x_nom + d_x, u_nom + d_u of the last x-step (isls.py:684-687); the setter evaluates its cost
@@ -157,7 +214,45 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     self.admm_iters = e.admm_iters.cpu().numpy()
     self.admm_logs = logbuf.cpu().numpy()
     self.outer_iters = np.array([len(h) - 1 for h in hist])
-    du_out = du[0].reshape(B, N * m).cpu().numpy()
-    phi_out = du[1:].permute(1, 2, 3, 0).reshape(B, N * m, C - 1).cpu().numpy()
-    self._dx_columns = dx.permute(1, 2, 3, 0).reshape(B, N * n, C).cpu().numpy()
+    self._dx_columns, xu = cs.columns()
+    du_out, phi_out = xu[..., 0], xu[..., 1:]
     return (du_out[0], phi_out[0]) if B == 1 else (du_out, phi_out)
+
+
+def admm_sls_columns(self, project_x, project_u, max_iter, rho_x, rho_u, alpha, tol, PHI_U):
+    """`SLS.ADMM_SLS` with state constraints (isls/sls.py:319-454) on the feedback columns: absolute coordinates, columns
+    [d, phi] with respect to the initial position (dim = x_dim / 2), no line search (the model is linear), z and lmb start
+    at zero, stop rules with the relative tolerance 1e-2 (sls.py:417-430).  project_x / project_u: `ConvexSets` over the
+    rows, or the reference's callables `rows -> rows`.  Returns (du, phi_u, logs [iterations, B, 2], iterations [B])."""
+    e = self.engine
+    B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
+    p = n // 2
+    C = p + 1
+    cs = ColumnSolver(e, C, project_x, project_u, nominal_in_projection=False)
+    # compute_Rr_Qr(dp=False) block-diagonal weights as per-step blocks; they enter the Hessians whether or not the block is
+    # projected (sls.py:342-349).  A zero rho is a zero block, not "no weight".
+    Qr, Rr = self.compute_Rr_Qr(rho_x=rho_x if rho_x is not None else 0.0, rho_u=rho_u if rho_u is not None else 0.0, dp=True)
+    self._set_reg(Qr, Rr, np.zeros(N * n), np.zeros(N * m))
+    self._expand_abs()
+    e.status.zero_()
+    ones = torch.ones(B, dtype=torch.int32, device=e.device)
+    cs.prepare(ones)
+    if (e.status.cpu().numpy() & capi.ST_NOT_PD).any():
+        raise np.linalg.LinAlgError("Singular matrix")
+    cs.restart(ones)
+    J = int(max_iter)
+    logbuf = torch.zeros(J, B, 2, dtype=e.dtype, device=e.device)
+    done = 0
+    for j in range(J):
+        cs.x_step()
+        done = j + 1
+        if not cs.constrained:                                                  # both residuals are zero: the loop stops at once
+            e.admm_iters.fill_(1)
+            break
+        cs.z_step(alpha, tol, 1e-2, log_row=logbuf[j])
+        if not bool(e.admm_active.any().item()):
+            break
+    _, xu = cs.columns()
+    du = xu[..., 0]
+    phi_u = np.concatenate([xu[..., 1:], np.broadcast_to(PHI_U[:, p:], (B,) + PHI_U[:, p:].shape)], axis=-1)
+    return du, phi_u, logbuf[:done].cpu().numpy(), e.admm_iters.cpu().numpy()

@@ -290,12 +290,23 @@ class SLS(Base):
         `project_u` is a `projections.ConvexSets` acting on the rows y = [d_u, phi_u] of the (N m) x (1 + n/2) variable
         (e.g. `projections.chance_constraint_rows`); its A / b / par arrays may carry a leading batch axis for problems
         that differ in bound or variance, and `zs` may be given per problem.  The set-up (transfer matrices, the (N m)^2
-        inverse) is host numpy, the ADMM loop of all problems is one device launch.  Returns du, phi_u[, logs]."""
-        if project_x:
-            raise NotImplementedError("ADMM_SLS with state constraints (project_x) is not built")
-        if not isinstance(project_u, ConvexSets):
-            raise NotImplementedError("ADMM_SLS runs its projection on the device: pass a projections.ConvexSets "
-                                      "(e.g. projections.chance_constraint_rows)")
+        inverse) is host numpy, the ADMM loop of all problems is one device launch.  With `project_x` (a `ConvexSets` over
+        the rows [d_x, phi_x], or the reference's callable on the (N n) x (1 + n/2) array), a non-zero `rho_x`, or callables,
+        the iteration runs over the feedback columns with the Riccati kernels instead.  Returns du, phi_u[, logs]."""
+        has_rho_x = rho_x is not None and np.any(np.asarray(rho_x) != 0)
+        if project_x or has_rho_x or not isinstance(project_u, ConvexSets):
+            # state constraints, state weights or projections given as the reference's callables: ADMM over the feedback
+            # columns with the Riccati kernels (robust.py) instead of the one-launch kernel with the dense inverse
+            from .robust import admm_sls_columns
+            self.l_side_invs = None
+            PHI_U, _ = self.solve_sls()
+            du, phi_u, lg, iters = admm_sls_columns(self, project_x, project_u, max_iter, rho_x, rho_u, alpha, tol, PHI_U)
+            self.sls_iters = iters
+            if self.batch == 1:
+                du, phi_u = du[0], phi_u[0]
+            if not log:
+                return du, phi_u
+            return du, phi_u, ([lg[j, 0] for j in range(int(iters[0]))] if self.batch == 1 else lg)
         e = self.engine
         B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
         p = n // 2

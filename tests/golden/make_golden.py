@@ -892,8 +892,58 @@ def gen_batch_ilqr():
     save("g10_batch_ilqr.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G11: SLS.ADMM_SLS with state AND control chance constraints ("LQR and SLS with state bounds.ipynb" cells 12-17) at N=40
+# ---------------------------------------------------------------------------------------------
+def gen_sls_state():
+    import contextlib
+    import io
+    from scipy.stats import norm
+    from isls import SLS as RefSLS
+    from isls.utils import get_double_integrator_AB as ref_di
+    N, n, m, p = 40, 2, 1, 1
+    A, B = ref_di(1, nb_deriv=2, dt=1.0 / N)
+    out = dict(A=A, B=B)
+    res = dict(du=[], phi_u=[], logs=[], n_it=[], rho_x=[])
+    for b, (target, upper_u, var_x0, conf) in enumerate(((1.0, 3.0, 0.02, 0.9), (0.8, 2.5, 0.01, 0.95))):
+        sls = RefSLS(n, m, N)
+        sls.AB = [A, B]
+        zs, Qs = np.stack([np.zeros(n), [target, 0.0]]), np.stack([np.zeros((n, n)), 1e6 * np.eye(n)])
+        seq = np.zeros(N, dtype=np.int32)
+        seq[N - 1] = 1
+        sls.set_quadratic_cost(zs, Qs, seq, 1e-2)
+        psi_inv = norm.ppf(conf)
+        mu, sigma = np.array([1.0, 0.0]), np.array([0.0, var_x0])
+        Au = np.diag(np.sqrt(sigma))
+        A_ = [np.concatenate([Au, (-mu / psi_inv)[None]], 0), np.concatenate([Au, (mu / psi_inv)[None]], 0)]
+        b_u = [np.append(np.zeros(2), upper_u / psi_inv), np.append(np.zeros(2), upper_u / psi_inv)]
+        # final position within [target - 0.05, target + 0.05], final velocity pinned to 0 (cell 16), all in the chance sense
+        b_pos = [np.append(np.zeros(2), (target + 0.05) / psi_inv), np.append(np.zeros(2), -(target - 0.05) / psi_inv)]
+        b_vel = [np.append(np.zeros(2), 0.0), np.append(np.zeros(2), 0.0)]
+        kw = dict(projections=[refproj.project_soc_unit] * 2, rho=1e1, max_iter=20, threshold=1e-2)
+        project_u = lambda y: refproj.project_set_convex(y, A_, b_u, **kw)        # noqa: E731
+
+        def project_x(x):
+            x_ = x.copy()
+            x_[-2:-1] = refproj.project_set_convex(x_[-2:-1], A_, b_pos, **kw)
+            x_[-1:] = refproj.project_set_convex(x_[-1:], A_, b_vel, **kw)
+            return x_
+        rho_x = np.zeros((N, n, n))
+        rho_x[-1, 0, 0] = rho_x[-1, 1, 1] = 1e3
+        with contextlib.redirect_stdout(io.StringIO()):
+            du, phi_u, logs = sls.ADMM_SLS(project_u=project_u, project_x=project_x, max_iter=30, rho_x=rho_x, rho_u=1e-3,
+                                           alpha=1.0, tol=1e-5, verbose=0, log=True)
+        lg = np.full((30, 2), np.nan)
+        lg[:len(logs)] = np.stack(logs)
+        res["du"].append(du), res["phi_u"].append(phi_u), res["logs"].append(lg), res["n_it"].append(len(logs)), res["rho_x"].append(rho_x)
+        print("sls state problem", b, "iterations", len(logs), "final residuals", logs[-1], "max |du|", np.max(np.abs(du)))
+    out.update({k_: np.stack(v) for k_, v in res.items()})
+    out.update(targets=np.array([1.0, 0.8]), upper_u=np.array([3.0, 2.5]), var_x0=np.array([0.02, 0.01]), conf=np.array([0.9, 0.95]))
+    save("g11_sls_state.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm", "batch_ilqr"]
+    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm", "batch_ilqr", "sls_state"]
     for w in which:
         {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections, "sls": gen_sls,
-         "tassa": gen_tassa, "isls_admm": gen_isls_admm, "batch_ilqr": gen_batch_ilqr}[w]()
+         "tassa": gen_tassa, "isls_admm": gen_isls_admm, "batch_ilqr": gen_batch_ilqr, "sls_state": gen_sls_state}[w]()

@@ -94,6 +94,47 @@ def test_sls_batch_form_through_the_riccati_pass(golden, tag, N):
         assert abs(np.max(ub) - 5.000018035934772) < 1e-7          # control bounds.ipynb:204-207
 
 
+def test_sls_admm_with_state_constraints(golden):
+    """SLS.ADMM_SLS(project_x=..., project_u=...) as the state-bounds notebook calls it (cells 12-17: the callables are
+    closures over project_set_convex acting on single rows of the (N n) x 2 state variable) against the unmodified
+    reference (G11).  Ours iterates over the feedback columns with the Riccati kernels; the reference inverts the dense
+    (N m)^2 normal equations."""
+    import isls
+    from isls.projections import project_set_convex, project_soc_unit
+    from scipy.stats import norm
+    g = golden("g11_sls_state.npz")
+    N, n = 40, 2
+    for b in range(2):
+        target, upper_u, var_x0, conf = (float(g[k][b]) for k in ("targets", "upper_u", "var_x0", "conf"))
+        sls = isls.SLS(2, 1, N)
+        sls.AB = [g["A"], g["B"]]
+        seq = np.zeros(N, dtype=np.int32)
+        seq[N - 1] = 1
+        sls.set_quadratic_cost(np.stack([np.zeros(n), [target, 0.0]]), np.stack([np.zeros((n, n)), 1e6 * np.eye(n)]), seq, 1e-2)
+        psi_inv = norm.ppf(conf)
+        mu, sigma = np.array([1.0, 0.0]), np.array([0.0, var_x0])
+        Au = np.diag(np.sqrt(sigma))
+        A_ = [np.concatenate([Au, (-mu / psi_inv)[None]], 0), np.concatenate([Au, (mu / psi_inv)[None]], 0)]
+        b_u = [np.append(np.zeros(2), upper_u / psi_inv), np.append(np.zeros(2), upper_u / psi_inv)]
+        b_pos = [np.append(np.zeros(2), (target + 0.05) / psi_inv), np.append(np.zeros(2), -(target - 0.05) / psi_inv)]
+        b_vel = [np.append(np.zeros(2), 0.0), np.append(np.zeros(2), 0.0)]
+        kw = dict(projections=[project_soc_unit] * 2, rho=1e1, max_iter=20, threshold=1e-2)
+        project_u = lambda y: project_set_convex(y, A_, b_u, **kw)             # noqa: E731
+
+        def project_x(x):
+            x_ = x.copy()
+            x_[-2:-1] = project_set_convex(x_[-2:-1], A_, b_pos, **kw)
+            x_[-1:] = project_set_convex(x_[-1:], A_, b_vel, **kw)
+            return x_
+        du, phi_u, logs = sls.ADMM_SLS(project_u=project_u, project_x=project_x, max_iter=30, rho_x=g["rho_x"][b], rho_u=1e-3,
+                                       alpha=1.0, tol=1e-5, verbose=0, log=True)
+        n_it = int(g["n_it"][b])
+        assert len(logs) == n_it
+        assert rel(np.stack(logs), g["logs"][b][:n_it]) < 1e-6
+        assert rel(du, g["du"][b]) < 1e-7 and rel(phi_u[:, :1], g["phi_u"][b][:, :1]) < 1e-7
+        assert phi_u.shape == g["phi_u"][b].shape and rel(phi_u, g["phi_u"][b]) < 1e-3   # tail columns: solve_sls' Woodbury chain (see G7)
+
+
 def test_sls_replanning_and_open_loop_helpers():
     """initialize_replanning_procedure / replan_feedforward (isls/sls.py:244-248), u_optimal / x_optimal and
     get_trajectory_batch (isls/sls_base.py:55-74): replanning the feed-forward term for moved targets equals the
@@ -319,7 +360,7 @@ def test_unbuilt_paths_fail_loudly():
         s.solve(method='sls')
     sl = isls.SLS(2, 1, 20)
     with pytest.raises(NotImplementedError):
-        sl.ADMM_SLS()
+        sl.get_trajectory_dp(np.zeros(2), np.zeros((20, 1, 2)), np.zeros((20, 1)), noise_scale=0.1)
 
 
 def test_sls_config5_api(golden):
