@@ -332,7 +332,7 @@ def isls_admm_main(args):
     from scipy.stats import norm
     torch.cuda.set_device(0)
     B, N = (args.batch if args.batch != 4096 else 1024), args.horizon
-    J, L, outer = 10, 30, max(1, args.steps // 5)
+    J, L, outer = 10, 30, max(1, args.steps)
     cfg = P.config3(batch=B, N=N, seed=0)
     cfg["u0"] = np.zeros_like(cfg["u0"])
     cs = chance_constraint_rows(3, 6.0, -6.0, 0.1, float(norm.ppf(0.82)), rho=10.0, max_iter=100, threshold=1e-4)
@@ -353,11 +353,11 @@ def isls_admm_main(args):
     s.isls_admm(3, None, max_line_search=L, k_max=outer, project_u=cs, rho_u=1.0, max_admm_iter=J, threshold=0.0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    done = float(np.mean(s.outer_iters))
+    done = float(np.max(s.outer_iters))               # outer iterations the batch ran (problems that met the reference's stop rules idle)
     out = {"metric": "isls_admm outer iterations/sec (3R arm, robust control bounds)", "value": done / dt, "unit": "iterations/s",
            "n_gpus": 1, "dtype": "f64", "data": "synthetic", "higher_is_better": True,
            "config": {"workload": "isls_admm: 3R arm, chance constraint on u w.r.t. q0 (dim 3)", "batch": B, "horizon": N,
-                      "admm_iters_J": J, "line_search_L": L, "outer_iterations_run": done},
+                      "admm_iters_J": J, "line_search_L": L, "outer_iterations_run": done, "outer_iterations_mean_per_problem": float(np.mean(s.outer_iters))},
            "ms_per_outer_iteration": 1e3 * dt / done, "problem_iterations_per_s": B * done / dt,
            "final_cost_mean": float(np.mean(s.cost))}
     if not args.no_cpu_baseline:
