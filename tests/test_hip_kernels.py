@@ -227,11 +227,13 @@ def test_feedforward_on_packed_records(dual, golden, which, ff_nseg):
     _report(dk)
 
 
-def test_fp32_kernels(dual):
-    """fp32 build of every kernel against the fp32 oracle (north star: 1e-4 fp32)."""
+@pytest.mark.parametrize("ff_record,ff_nseg", [(False, 1), (True, 1), (True, 3)])
+def test_fp32_kernels(dual, ff_record, ff_nseg):
+    """fp32 build of every kernel against the fp32 oracle (north star: 1e-4 fp32); the feed-forward pass in its array form
+    and on the packed records of the gain pass, sequential and time-parallel."""
     cfg = P.config2(batch=16, N=100, seed=4)
     pa = problem_arrays(cfg, range(10), dtype=np.float32)
-    dk = dual(tol=1e-4)
+    dk = dual(tol=1e-4, ff_record=ff_record, ff_nseg=ff_nseg)
     dk.int_exact = False            # near-ties of the arg-min may flip in fp32
     d = OracleDriver(dk, pa, rho_u=cfg["rho_u"], relax=cfg["relax"], dtype=np.float32)
     d.run(2, 20, 3, 0.0)
