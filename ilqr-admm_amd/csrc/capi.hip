@@ -58,7 +58,7 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
             isls_ff_prepare_args pr = {};
             pr.B = f.B; pr.N = f.N; pr.n = f.n; pr.m = f.m; pr.solve_mode = f.solve_mode;
             pr.A = f.A; pr.Bm = f.Bm; pr.K = f.K; pr.Quu = f.Quu; pr.fac = f.fac; pr.Qux = f.Qux;
-            pr.active = f.active; pr.seg = f.seg;
+            pr.active = f.active; pr.seg = f.seg; pr.rec = f.rec;
             ScopedTimer tm(4, s);
             if ((rc = launch_ff_prepare<T>(pr, s)) != ISLS_OK) return rc;
         }

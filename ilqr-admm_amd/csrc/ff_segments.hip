@@ -35,6 +35,7 @@ struct FfPrepP {
     int B, N, mode, tpw, nseg, seg_len;
     View<T> A, Bm;
     const T *K, *Quu, *fac, *Qux;
+    const T *rec;                  // packed step records of the gain pass (nullable): the operators come from those instead
     T *G, *Psi;
     const int32_t *active;
 };
@@ -203,6 +204,117 @@ __global__ __launch_bounds__(64) void ff_prepare_kernel(FfPrepP<T> p)
     }
 }
 
+// The same operators from the packed step records [A+BK | B | K | fac] of the gain pass (isls_gain_args.rec): the
+// homogeneous recursion is  psi' = (A + B K)' psi,  kappa = -Quu^-1 B' psi  -- 63 multiply-adds and one 81-word record per
+// step against 126 and six arrays (108 words) in the array form above; same slots (trajectory, segment), one lane per unit
+// vector.  Records are blocked by wavefront of the gain pass: [b / TR][t][b % TR][RW], TR = 64 / (n + m).
+template <typename T, int NX, int NU, int D>
+__global__ __launch_bounds__(64) void ff_prepare_rec_kernel(FfPrepP<T> p)
+{
+    constexpr int GP = NX, MAXTPW = kWave / GP, TR = kWave / (NX + NU);
+    constexpr int PHI_OFF = 0, B_OFF = NX * NX, FAC_OFF = B_OFF + NX * NU + NU * NX, RW = FAC_OFF + NU * NU, DUMP_OFF = RW;
+    constexpr int RECP = ((DUMP_OFF + 1) | 1), JR = (RW + GP - 1) / GP;
+    __shared__ T lds[MAXTPW * 2 * RECP];
+
+    const int TPW = p.tpw, N = p.N, SL = p.seg_len, NS1 = p.nseg - 1;
+    const int lane = threadIdx.x;
+    const int s = (lane / GP < TPW) ? lane / GP : TPW - 1;     // surplus lanes ride along in the last slot (stage nothing)
+    const int j = lane - s * GP;
+    const bool extra = j >= GP;
+    const int64_t Q = (int64_t)p.B * NS1;
+    const int64_t q0 = (int64_t)blockIdx.x * TPW, q = q0 + s;
+    const bool inrange = q < Q && !extra;
+    const int64_t qq = q < Q ? q : q0;                         // idle slots shadow the block's first slot (loads only)
+    const int b = (int)(qq / NS1), sg = (int)(qq - (int64_t)b * NS1);
+    const bool valid = inrange && (p.active == nullptr || p.active[b] != 0);
+    const int t_first = sg * SL + SL - 1;                      // steps t_first, t_first-1, .. sg*SL
+    const int jl = extra ? 0 : j;
+    T *recs = lds + s * 2 * RECP;
+    const T *base = p.rec + (((int64_t)(b / TR) * N + t_first) * TR + (b % TR)) * RW;    // record (b, t_first); t-1 is TR*RW below
+    int off[JR], dst[JR];
+#pragma unroll
+    for (int a = 0; a < JR; ++a) {
+        const int e = jl + GP * a;
+        off[a] = e < RW ? e : RW - 1;
+        dst[a] = (!extra && e < RW) ? e : DUMP_OFF;
+    }
+    T rr[D][JR];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int it = d < SL ? d : SL - 1;
+#pragma unroll
+        for (int a = 0; a < JR; ++a) rr[d][a] = base[off[a] - (int64_t)it * (TR * RW)];
+    }
+    T psi[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) psi[i] = (i == jl) ? T(1) : T(0);
+    T *gout = p.G + (((int64_t)b * N + t_first) * NU) * NX + jl;
+    const int mode = p.mode;
+    for (int itb = 0; itb < SL; itb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int it = itb + d;
+            const bool live = it < SL;
+            T *rec = recs + (it & 1) * RECP;
+#pragma unroll
+            for (int a = 0; a < JR; ++a) rec[dst[a]] = rr[d][a];
+            slot_sync();
+            {
+                const int itn = it + D < SL ? it + D : SL - 1;  // refill (clamped, unconditional)
+#pragma unroll
+                for (int a = 0; a < JR; ++a) rr[d][a] = base[off[a] - (int64_t)itn * (TR * RW)];
+            }
+            T pn[NX], qu[NU], kap[NU];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                T acc = T(0);
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc += rec[PHI_OFF + k * NX + i] * psi[k];
+                pn[i] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                T acc = T(0);
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc += rec[B_OFF + k * NU + r] * psi[k];
+                qu[r] = acc;
+            }
+            if (mode == ISLS_SOLVE_CHOL) {
+                T U[NU][NU], rd[NU], x[NU];
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) U[r][c] = rec[FAC_OFF + r * NU + c];
+                    rd[r] = U[r][r];
+                }
+                chol_solve<NU>(U, rd, qu, x);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) kap[r] = -x[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+                    T acc = T(0);
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) acc += rec[FAC_OFF + r * NU + c] * qu[c];
+                    kap[r] = -acc;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) psi[i] = live ? pn[i] : psi[i];
+            if (valid && live) {
+#pragma unroll
+                for (int r = 0; r < NU; ++r) gout[r * NX] = kap[r];            // G_t[:, j]
+            }
+            gout -= NU * NX;
+        }
+    }
+    if (valid && sg >= 1) {
+        T *po = p.Psi + (((int64_t)b * p.nseg + sg) * NX) * NX + jl;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) po[i * NX] = psi[i];                      // Psi_s[:, j]
+    }
+}
+
 template <typename T, int NX, int NU>
 __global__ __launch_bounds__(256) void ff_stitch_kernel(int B, int N, int nseg, int SL, const T *__restrict__ G,
                                                         const T *__restrict__ Psi, const T *__restrict__ vseg,
@@ -255,10 +367,27 @@ bool ff_seg_enabled(const isls_ffseg &sg) { return sg.nseg >= 2 && sg.G != nullp
 template <typename T>
 int launch_ff_prepare(const isls_ff_prepare_args &a, hipStream_t s)
 {
-    if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.K || !a.Quu || !a.fac || !a.Qux) return ISLS_ERR_ARG;
+    if (a.B < 0 || a.N < 1) return ISLS_ERR_ARG;
+    if (!a.rec && (!a.A.p || !a.Bm.p || !a.K || !a.Quu || !a.fac || !a.Qux)) return ISLS_ERR_ARG;
     if (a.solve_mode != ISLS_SOLVE_CHOL && a.solve_mode != ISLS_SOLVE_INV) return ISLS_ERR_ARG;
     if (!ff_seg_enabled(a.seg)) return ISLS_OK;                // sequential recursion: nothing to prepare
     if (!seg_ok(a.seg, a.N)) return ISLS_ERR_ARG;
+    if (a.rec) {                                               // operators from the packed records of the gain pass
+        if (a.B == 0) return ISLS_OK;
+        FfPrepP<T> pr = {};
+        pr.B = a.B; pr.N = a.N; pr.mode = a.solve_mode; pr.nseg = a.seg.nseg; pr.seg_len = a.seg.seg_len;
+        pr.rec = (const T *)a.rec; pr.G = (T *)a.seg.G; pr.Psi = (T *)a.seg.Psi; pr.active = a.active;
+        const int64_t Qr = (int64_t)a.B * (a.seg.nseg - 1);
+#define CALLR(NX_, NU_)                                                                                      \
+    {                                                                                                        \
+        pr.tpw = kWave / NX_;                                                                                \
+        const int grid = (int)((Qr + pr.tpw - 1) / pr.tpw);                                                  \
+        hipLaunchKernelGGL((ff_prepare_rec_kernel<T, NX_, NU_, kPrepDepth>), dim3(grid), dim3(64), 0, s, pr); \
+    }
+        ISLS_DISPATCH_DIMS(a.n, a.m, CALLR)
+#undef CALLR
+        return check_launch();
+    }
     if ((int64_t)a.N * a.n * a.n * 64 >= ((int64_t)1 << 31) || a.A.sb * 64 + a.A.st * a.N >= ((int64_t)1 << 31) ||
         a.Bm.sb * 64 + a.Bm.st * a.N >= ((int64_t)1 << 31))
         return ISLS_ERR_UNSUPPORTED;
@@ -266,7 +395,7 @@ int launch_ff_prepare(const isls_ff_prepare_args &a, hipStream_t s)
     FfPrepP<T> p;
     p.B = a.B; p.N = a.N; p.mode = a.solve_mode; p.nseg = a.seg.nseg; p.seg_len = a.seg.seg_len;
     p.A = View<T>(a.A); p.Bm = View<T>(a.Bm);
-    p.K = (const T *)a.K; p.Quu = (const T *)a.Quu; p.fac = (const T *)a.fac; p.Qux = (const T *)a.Qux;
+    p.K = (const T *)a.K; p.Quu = (const T *)a.Quu; p.fac = (const T *)a.fac; p.Qux = (const T *)a.Qux; p.rec = nullptr;
     p.G = (T *)a.seg.G; p.Psi = (T *)a.seg.Psi; p.active = a.active;
     const int64_t Q = (int64_t)a.B * (a.seg.nseg - 1);
 #define CALL(NX_, NU_)                                                                                    \

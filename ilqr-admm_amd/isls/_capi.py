@@ -62,7 +62,7 @@ class FfPrepareArgs(C.Structure):
                 ("solve_mode", C.c_int32), ("_pad", C.c_int32),
                 ("A", View), ("Bm", View),
                 ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
-                ("active", C.c_void_p), ("seg", FfSeg)]
+                ("active", C.c_void_p), ("seg", FfSeg), ("rec", C.c_void_p)]
 
 
 class RolloutArgs(C.Structure):
@@ -370,13 +370,14 @@ class Kernels:
         return FfSeg(nseg=nseg, seg_len=int(seg_len), G=_ptr(G), Psi=_ptr(Psi), v=_ptr(v))
 
     @staticmethod
-    def ff_prepare_args(A, Bm, K, Quu, fac, Qux, seg, solve_mode=SOLVE_CHOL, active=None):
+    def ff_prepare_args(A, Bm, K, Quu, fac, Qux, seg, solve_mode=SOLVE_CHOL, active=None, rec=None):
         B, N, m, n = K.shape
         a = FfPrepareArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode, seg=seg)
         a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
         a.K, a.Quu = _ptr(_dense(K, (B, N, m, n), "K")), _ptr(_dense(Quu, (B, N, m, m), "Quu"))
         a.fac, a.Qux = _ptr(_dense(fac, (B, N, m, m), "fac")), _ptr(_dense(Qux, (B, N, m, n), "Qux"))
         a.active = _ptr(active)
+        a.rec = _ptr(_record(rec, B, N, n, m))
         return a
 
     @staticmethod

@@ -298,9 +298,9 @@ class Engine:
             self._seg_bufs = (z(self.B, self.N, self.m, self.n), z(self.B, nseg, self.n, self.n), z(self.B, nseg, self.n))
         return capi.Kernels.ff_seg(*self._seg_bufs, seg_len)
 
-    def feedforward_prepare(self, seg, active=None):
+    def feedforward_prepare(self, seg, active=None, rec=None):
         self.kern.riccati_ff_prepare(self.A, self.Bm, self.K, self.Quu, self.fac, self.Qux, seg,
-                                     solve_mode=self.solve_mode, active=active, stream=_stream_ptr())
+                                     solve_mode=self.solve_mode, active=active, rec=rec, stream=_stream_ptr())
 
     # ---- one outer iteration, enqueued by the C driver in one call --------------------------------------------
     def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None, ff_nseg=None):

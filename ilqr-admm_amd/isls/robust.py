@@ -71,7 +71,7 @@ class ColumnSolver:
         e.gain(active=active, rec=self.rec)
         self.seg = e.ff_seg()
         if self.seg is not None:
-            e.feedforward_prepare(self.seg, active=active)
+            e.feedforward_prepare(self.seg, active=active, rec=self.rec)
         self.Cuu = e.hessians()[1]
 
     def restart(self, active):

@@ -187,6 +187,7 @@ typedef struct isls_ff_prepare_args {
     const void *K, *Quu, *fac, *Qux;
     const int32_t *active;
     isls_ffseg seg;
+    const void *rec;       /* nullable: the gain pass's packed records (isls_gain_args.rec); A .. Qux are then not read */
 } isls_ff_prepare_args;
 
 int isls_riccati_ff_prepare_f64(const isls_ff_prepare_args *a, void *stream);

@@ -83,8 +83,9 @@ class DualKernels:
         nan = lambda *shape: torch.full(shape, float("nan"), dtype=K.dtype, device=K.device)   # noqa: E731
         self._seg_bufs = (nan(B, N, m, n), nan(B, nseg, n, n), nan(B, nseg, n))
         seg = capi.Kernels.ff_seg(*self._seg_bufs, seg_len)
+        rec = self._rec if (self.ff_record and self._rec is not None and self._rec_dims == (B, N)) else None
         self.hip.riccati_ff_prepare(A, Bm, K, Quu, fac, Qux, seg, solve_mode=dkw.get("solve_mode", capi.SOLVE_CHOL),
-                                    active=dkw.get("active"))
+                                    active=dkw.get("active"), rec=rec)
         return seg
 
     def __getattr__(self, name):
