@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 KIND_NAMES = ["riccati_gain_kernel", "riccati_ff_kernel", "rollout_kernel", "admm_update_kernel", "ff_prepare_kernel"]
 # kernels behind each timed family (isls_timing kind): the time-parallel feed-forward pass is two launches
 KIND_KERNELS = [["riccati_gain_kernel"], ["riccati_ff_kernel", "riccati_ffrec_kernel", "ff_stitch_kernel"], ["rollout_kernel"],
-                ["admm_update_kernel"], ["ff_prepare_kernel"]]
+                ["admm_update_kernel"], ["ff_prepare_kernel", "ff_prepare_rec_kernel"]]
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 
 
