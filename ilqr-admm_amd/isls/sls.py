@@ -172,7 +172,7 @@ class SLS(Base):
         which never acts on the state and which the dense form sets to (R + Rr)^-1 Rr (z_u - lmb_u) at t = N-1 (SURVEY 8a
         quirk i); z starts at the unconstrained solution (sls.py:268-270).  Returns (x_flat, u_flat[, logs])."""
         out = self._admm_lqt(x0, project_x, project_u, max_iter, rho_x, rho_u, alpha, tol, log, batch_form=True)
-        return out[:2] + out[4:]
+        return out if len(out) <= 3 else out[:2] + out[4:]        # the device route also carries K, k (as ADMM_LQT_DP returns them)
 
     def solve_batch(self, x0):
         """isls/sls.py:60-82: the unconstrained batch-form LQT solution equals the Riccati solution rolled out from x0 (the
@@ -180,14 +180,52 @@ class SLS(Base):
         K, k = self.solve_dp()
         return self.get_trajectory_dp(x0, K, k)
 
+    def _admm_lqt_host(self, x0, px, pu, max_iter, rho_x, rho_u, alpha, tol, log, batch_form):
+        """Projections given as arbitrary numpy callables (e.g. the Dykstra closures of the spherical-obstacle notebook):
+        the x-step runs on the device, the z-step is the caller's function inside the host mirror of the reference's ADMM()
+        (isls/admm.py).  One problem at a time, as the reference; device descriptors (Box, ConvexSets) are the batched route."""
+        from .admm import ADMM
+        if self.batch != 1:
+            raise NotImplementedError("projections given as Python callables run one problem at a time (batch=1); describe the "
+                                      "set with projections.Box / ConvexSets for the batched device route")
+        e = self.engine
+        N, n, m = self.N, self.x_dim, self.u_dim
+        Qr, Rr = self.compute_Rr_Qr(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None, dp=True)
+        z_init = {}
+        if batch_form:                                          # z <- unconstrained solution (sls.py:266-270)
+            xs, us = self.solve_batch(x0)
+            z_init = dict(z_x_init=np.asarray(xs).reshape(-1).copy(), z_u_init=np.asarray(us).reshape(-1).copy())
+        self.solve_dp(Rr=Rr, Qr=Qr, xr=np.zeros(N * n), ur=np.zeros(N * m))
+        last = None
+        if batch_form and pu is not None:                       # the dense form's last control (see ADMM_LQT_Batch)
+            R_, Rr_ = np.eye(m) * self.u_std, np.asarray(Rr[-1], dtype=np.float64)
+            last = np.linalg.inv(R_ + Rr_) @ Rr_
+        x0t = e._t(self._batched(x0, 1))
+        one = torch.ones(1, dtype=e.dtype, device=e.device)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def f_argmin(x_reg, u_reg):
+            if px is not None:
+                e.zx.copy_(e._t(np.asarray(x_reg).reshape(1, N, n)))
+            if pu is not None:
+                e.zu.copy_(e._t(np.asarray(u_reg).reshape(1, N, m)))
+            e.kern.riccati_ff(e.A, e.Bm, e.c0x, e.c0u, e.K, e.Quu, e.fac, e.Qux, e.k, Qr=e.Qr, Rr=e.Rr, zx=e.zx, lx=e.lx,
+                              zu=e.zu, lu=e.lu, solve_mode=capi.SOLVE_INV, stream=stream)
+            e.kern.rollout_ls(e.model, e.model_par, e.K, e.k, e.xhat, e.uhat, one, e.Qtab, e.ztab, e.seq, e.u_std, e.xx, e.xu,
+                              x0=x0t, flags=capi.RO_ABSOLUTE, q_nonzero=e.q_nonzero, stream=stream)
+            x, u = e.xx.cpu().numpy().astype(np.float64).reshape(-1), e.xu.cpu().numpy().astype(np.float64).reshape(-1)
+            if last is not None:
+                u[-m:] = last @ np.asarray(u_reg).reshape(N, m)[-1]
+            return (x, u) if batch_form else (x, u, self._out(e.K), self._out(e.k))
+        return ADMM(n * N, m * N, f_argmin, project_x=px if px is not None else False, project_u=pu if pu is not None else False,
+                    alpha=alpha, max_iter=max_iter, tol=tol, log=log, **z_init)
+
     def _admm_lqt(self, x0, project_x, project_u, max_iter, rho_x, rho_u, alpha, tol, log, batch_form):
         e = self.engine
         B, N, n, m = self.batch, self.N, self.x_dim, self.u_dim
         px, pu = self._projection(project_x, n), self._projection(project_u, m)
-        for p_ in (px, pu):
-            if p_ is not None and not isinstance(p_, (Box, ConvexSets)):
-                raise NotImplementedError("ADMM_LQT_DP runs its projections on the device: pass a projections.Box (or a "
-                                          "callable that is recognisably a box) or a projections.ConvexSets")
+        if any(p_ is not None and not isinstance(p_, (Box, ConvexSets)) for p_ in (px, pu)):
+            return self._admm_lqt_host(x0, px, pu, max_iter, rho_x, rho_u, alpha, tol, log, batch_form)
         Qr, Rr = self.compute_Rr_Qr(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None, dp=True)
         self.solve_dp(Rr=Rr, Qr=Qr, xr=np.zeros(N * n), ur=np.zeros(N * m))
         sets = {}

@@ -942,8 +942,58 @@ def gen_sls_state():
     save("g11_sls_state.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G12: LQT-ADMM with an arbitrary numpy state projection (project_set_convex + Dykstra over quadratic shells):
+# "LQR and SLS with spherical obstacle avoidance.ipynb" cells 4-14 at N=60
+# ---------------------------------------------------------------------------------------------
+def spherical_obstacle_projection(projmod, x_dim, d, centres, radii):
+    """project_state of the notebook (cell 12) built from a projections module (the reference's or ours)."""
+    lowers = [0.5 * (1.1 * r) ** 2 for r in radii]
+    shells = [lambda x, lo=lo, c=c: projmod.project_quadratic(x - c, lo, 1e2) + c for lo, c in zip(lowers, centres)]
+    eyes, zeros = [np.eye(x_dim)] * len(radii), [np.zeros(x_dim)] * len(radii)
+
+    def project_state(x):
+        x_ = x.reshape(-1, d).copy()
+        x_[:, :x_dim] = projmod.project_set_convex(x_[:, :x_dim], eyes, zeros, shells, max_iter=5, verbose=0, threshold=1e-2)
+        x_[:, :x_dim] = projmod.project_set_convex_dykstra(x_[:, :x_dim], shells, max_iter=50, verbose=0, tol=1e-5)
+        return x_.flatten()
+    return project_state
+
+
+def gen_obstacles():
+    import contextlib
+    import io
+    from isls import SLS as RefSLS
+    from isls.utils import get_double_integrator_AB as ref_di
+    N, x_dim = 60, 2
+    d = 2 * x_dim
+    A, B = ref_di(x_dim, nb_deriv=2, dt=1.0 / N)
+    sls = RefSLS(d, x_dim, N)
+    sls.AB = [A, B]
+    zs, Qs = np.stack([np.zeros(d), [1.0, 1.0, 0.0, 0.0]]), np.stack([np.zeros((d, d)), 1e3 * np.eye(d)])
+    seq = np.zeros(N, dtype=np.int32)
+    seq[N - 1] = 1
+    sls.set_quadratic_cost(zs, Qs, seq, 1e-4)
+    centres, radii = [np.array([0.5, 0.5]), np.array([0.5, 0.2])], [0.1, 0.15]
+    project_state = spherical_obstacle_projection(refproj, x_dim, d, centres, radii)
+    rho_x = np.zeros((N, d, d))
+    rho_x[:, :x_dim, :x_dim] = np.eye(x_dim)
+    with contextlib.redirect_stdout(io.StringIO()):
+        # keeping points OUT of a ball is a non-convex projection: the iteration amplifies rounding differences by ~10x per
+        # iteration from iteration ~25 on (two runs of the same algorithm with a different summation order agree to 1e-12 for
+        # 25 iterations and to nothing after 45), so the vectors stop where the reference's own trace is still reproducible
+        xb, ub, logb = sls.ADMM_LQT_Batch(np.zeros(d), project_x=project_state, max_iter=20, rho_x=rho_x, alpha=1.0, tol=1e-3,
+                                          verbose=0, log=True)
+        xd, ud, Kd, kd, logd = sls.ADMM_LQT_DP(np.zeros(d), project_x=project_state, max_iter=25, rho_x=rho_x, tol=1e-4,
+                                               verbose=False, log=True)
+    print("obstacles: batch iterations", len(logb), "dp iterations", len(logd), "min distance to centre 0",
+          np.min(np.linalg.norm(xd.reshape(N, d)[:, :2] - centres[0], axis=1)))
+    save("g12_obstacles.npz", A=A, B=B, batch_x=xb, batch_u=ub, batch_logs=np.stack(logb), dp_x=xd, dp_u=ud, dp_k=kd,
+         dp_logs=np.stack(logd), centres=np.stack(centres), radii=np.array(radii))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm", "batch_ilqr", "sls_state"]
+    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm", "batch_ilqr", "sls_state", "obstacles"]
     for w in which:
         {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections, "sls": gen_sls,
-         "tassa": gen_tassa, "isls_admm": gen_isls_admm, "batch_ilqr": gen_batch_ilqr, "sls_state": gen_sls_state}[w]()
+         "tassa": gen_tassa, "isls_admm": gen_isls_admm, "batch_ilqr": gen_batch_ilqr, "sls_state": gen_sls_state, "obstacles": gen_obstacles}[w]()
