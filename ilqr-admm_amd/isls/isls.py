@@ -474,13 +474,41 @@ class iSLS(Base):
         self.cost_log.append(self.cost)
         return ok
 
-    # ---- closed-loop evaluation (isls/isls_base.py:62-71) -----------------------------------------------------
+    # ---- closed-loop evaluation (isls/isls_base.py:28-71) -----------------------------------------------------
+    def get_trajectory_batch(self, x0, us, noise_scale=0):
+        """Open loop: the control sequence us [N,m] (or [B,N,m]) applied from x0 (isls/isls_base.py:44-57) -- the notebooks'
+        way to turn initial controls into a nominal trajectory."""
+        us = np.asarray(us, dtype=np.float64)
+        return self.get_trajectory_dp(x0, np.zeros(us.shape[:-1] + (self.u_dim, self.x_dim)), us, noise_scale)
+
+    def _transfer_ltv(self, problem=0):
+        from . import sls_dense as dense
+        A, Bm = self.engine.A.cpu().numpy().astype(np.float64), self.engine.Bm.cpu().numpy().astype(np.float64)
+        b = min(problem, A.shape[0] - 1)
+        return dense.transfer_matrices_ltv(np.broadcast_to(A[b], (self.N,) + A.shape[-2:]), np.broadcast_to(Bm[b], (self.N,) + Bm.shape[-2:]))
+
+    # dense transfer matrices of the last linearisation (Base.AB's Sw / Su, isls/base.py:98-119; notebook-era names C / D):
+    # host numpy, built on demand for problem 0 of the batch -- the solvers themselves never form them
+    Sw = property(lambda self: self._transfer_ltv()[0])
+    Su = property(lambda self: self._transfer_ltv()[1])
+    C, D = Sw, Su
+
     def get_trajectory_dp(self, x0, K, k, noise_scale=0):
-        """u_t = K_t x_t + k_t, x_{t+1} = f(x_t, u_t) from x0 (absolute form), noise-free only."""
+        """u_t = K_t x_t + k_t, x_{t+1} = f(x_t, u_t) from x0 (absolute form), noise-free only.  x0 [n] (or [B,n]): one
+        trajectory per problem of the batch; x0 [M,n] with batch == 1: M initial states against the same controller."""
         if noise_scale:
             raise NotImplementedError("process noise is drawn on the host in the reference; not built")
         e = self.engine
+        x0 = np.asarray(x0, dtype=np.float64)
+        if x0.ndim == 2 and self.batch == 1 and x0.shape[0] != 1:      # Monte Carlo over initial states: a batch of M rollouts
+            mc = iSLS(self.x_dim, self.u_dim, self.N, batch=x0.shape[0], dtype=self.np_dtype, device=e.device)
+            mc.forward_model = self._forward_model
+            mc.engine.Qtab, mc.engine.ztab, mc.engine.seq, mc.engine.q_nonzero = e.Qtab, e.ztab, e.seq, e.q_nonzero
+            mc.engine.u_std, mc.engine.cost_model, mc.engine.cost_par = e.u_std, e.cost_model, e.cost_par
+            return mc.get_trajectory_dp(x0, K, k)
         x0 = self._batched(x0, 1)
+        if e.Qtab is None:                                       # no cost yet (the notebooks roll the initial controls out first)
+            e.set_quadratic_cost(np.zeros((1, self.x_dim)), np.zeros((1, self.x_dim, self.x_dim)), np.zeros(self.N, dtype=np.int32), 0.0)
         one = torch.ones(1, dtype=e.dtype, device=e.device)
         e.kern.rollout_ls(e.model, e.model_par, e._t(self._batched(K, 3)), e._t(self._batched(k, 2)), e.xhat, e.uhat, one,
                           e.Qtab, e.ztab, e.seq, e.u_std, e.xx, e.xu, x0=e._t(x0), flags=capi.RO_ABSOLUTE,

@@ -259,6 +259,33 @@ def test_isls_solve_cost_logs(golden, which):
 # ---------------------------------------------------------------------------------------------------------
 # iSLS.ilqr_admm (DP form) against the reference-composed O2 traces
 # ---------------------------------------------------------------------------------------------------------
+def test_isls_open_loop_and_monte_carlo_helpers():
+    """get_trajectory_batch (isls/isls_base.py:44-57) before any cost is set, Monte-Carlo get_trajectory_dp over M initial
+    states with batch == 1, and the dense Sw / Su (C / D) of the last linearisation (isls/base.py:98-119)."""
+    import isls
+    from isls import models
+    cfg = P.config4(batch=1, N=30, seed=1)
+    s = isls.iSLS(4, 2, 30)
+    s.forward_model = models.CarSimple(cfg["dt"])
+    f = P.car_f(cfg["dt"])
+    u = 0.1 * np.random.default_rng(0).standard_normal((30, 2))
+    x_ol, u_ol = s.get_trajectory_batch(cfg["x0"][0], u)
+    assert rel(x_ol, P.rollout_open_loop(f, cfg["x0"][0], u)) < 1e-12 and np.array_equal(u_ol, u)
+    x0s = cfg["x0"][0] + 0.05 * np.random.default_rng(1).standard_normal((7, 4))
+    K, k = 0.1 * np.random.default_rng(2).standard_normal((30, 2, 4)), u
+    xs, us = s.get_trajectory_dp(x0s, K, k)
+    assert xs.shape == (7, 30, 4)
+    x1, u1 = s.get_trajectory_dp(x0s[3], K, k)
+    assert np.array_equal(xs[3], x1) and np.array_equal(us[3], u1)
+    s.set_cost_variables(cfg["zs"][0] if cfg["zs"].ndim == 3 else cfg["zs"], cfg["Qs"], cfg["seq"], cfg["u_std"])
+    s.nominal_values = x_ol, u_ol
+    s.backward_pass_DP()                                          # linearises about the nominal
+    Sw, Su = s.Sw, s.Su
+    assert s.C is not None and Sw.shape == (120, 120) and Su.shape == (120, 60) and not Su[:, -2:].any()
+    A = s.engine.A.cpu().numpy()[0]
+    assert rel(Sw[4:8, :4], A[0]) < 1e-14 and rel(Sw[8:12, :4], A[1] @ A[0]) < 1e-13
+
+
 @pytest.mark.parametrize("name", ["arm", "car"])
 def test_isls_batch_form_ilqr(golden, name):
     """backward_pass_batch / iterate_once_batch / solve(method='batch') (isls/isls.py:156-228) against the reference's dense
