@@ -80,12 +80,12 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 #pragma unroll
             for (int j = 0; j < (NU * NX + G - 1) / G; ++j) {
                 const int e = i + G * j;
-                if (e < NU * NX) { p.K[o * NU * NX + e] = T(0); p.Qux[o * NU * NX + e] = T(0); }
+                if (e < NU * NX) { p.K[o * NU * NX + e] = T(0); if (p.Qux) p.Qux[o * NU * NX + e] = T(0); }
             }
 #pragma unroll
             for (int j = 0; j < (NU * NU + G - 1) / G; ++j) {
                 const int e = i + G * j;
-                if (e < NU * NU) { p.Quu[o * NU * NU + e] = T(0); p.fac[o * NU * NU + e] = T(0); }
+                if (e < NU * NU) { if (p.Quu) p.Quu[o * NU * NU + e] = T(0); if (p.fac) p.fac[o * NU * NU + e] = T(0); }
             }
         }
     }
@@ -195,8 +195,9 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 #pragma unroll
             for (int r = 0; r < NU; ++r) p.K[(o * NU + r) * NX + i] = Kc[r];
         }
-        if (valid) {
-            // cooperative store of [Qux Quu] rows
+        if (valid && p.Qux) {
+            // cooperative store of [Qux Quu] rows (skipped when the caller only wants K, fac and the packed records: every
+            // consumer of Qux / Quu then reads the records instead)
 #pragma unroll
             for (int j = 0; j < JQ; ++j) {
                 const int e = i + G * j;
@@ -207,6 +208,8 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                     else p.Quu[(o * NU + r) * NU + (c - NX)] = v;
                 }
             }
+        }
+        if (valid) {
             // factor: row i written by lane i < NU (the values are identical in every lane; the row is picked by selects)
             if (i < NU) {
 #pragma unroll
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                         const T vr = (p.mode == ISLS_SOLVE_CHOL) ? ((c == r) ? rd[r] : (c > r ? U[r][c] : T(0))) : inv[r][c];
                         v = (i == r) ? vr : v;
                     }
-                    p.fac[(o * NU + i) * NU + c] = v;
+                    if (p.fac) p.fac[(o * NU + i) * NU + c] = v;
                     if (p.rec) p.rec[orec * RW + RFAC + i * NU + c] = v;
                 }
             }
@@ -288,8 +291,9 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 template <typename T>
 int launch_gain(const isls_gain_args &a, hipStream_t s)
 {
-    if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.Cxx.p || !a.Cuu.p || !a.K || !a.Quu || !a.fac || !a.Qux)
-        return ISLS_ERR_ARG;
+    if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.Cxx.p || !a.Cuu.p || !a.K) return ISLS_ERR_ARG;
+    // Quu, fac, Qux: all three or none; none only with records (every consumer then reads those)
+    if ((!a.Quu || !a.Qux || !a.fac) && (!a.rec || a.Quu || a.Qux || a.fac)) return ISLS_ERR_ARG;
     if (a.solve_mode != ISLS_SOLVE_CHOL && a.solve_mode != ISLS_SOLVE_INV) return ISLS_ERR_ARG;
     if (a.B == 0) return ISLS_OK;
     GainP<T> p;

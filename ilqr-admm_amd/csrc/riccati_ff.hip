@@ -302,8 +302,8 @@ __global__ __launch_bounds__(64, OCC) void riccati_ff_kernel(FfP<T> p)
 template <typename T>
 int launch_ff(const isls_ff_args &a, hipStream_t s)
 {
-    if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.c0x.p || !a.c0u.p || !a.K || !a.Quu || !a.fac || !a.Qux || !a.k)
-        return ISLS_ERR_ARG;
+    if (a.B < 0 || a.N < 1 || !a.c0x.p || !a.c0u.p || !a.k) return ISLS_ERR_ARG;
+    if (!a.rec && (!a.A.p || !a.Bm.p || !a.K || !a.Quu || !a.fac || !a.Qux)) return ISLS_ERR_ARG;
     if (a.Qr.p && (!a.zx || !a.lx)) return ISLS_ERR_ARG;
     if (a.Rr.p && (!a.zu || !a.lu)) return ISLS_ERR_ARG;
     if (a.solve_mode != ISLS_SOLVE_CHOL && a.solve_mode != ISLS_SOLVE_INV) return ISLS_ERR_ARG;

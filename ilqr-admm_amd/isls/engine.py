@@ -257,7 +257,11 @@ class Engine:
         return self._ffrec
 
     def gain(self, active=None, rec=None):
-        self.kern.riccati_gain(self.A, self.Bm, *self.hessians(), self.K, self.Quu, self.fac, self.Qux,
+        """Gain pass; with `rec` the caller promises to run its feed-forward passes on the records, and Quu / fac / Qux
+        (which only those passes would read) are not written."""
+        full = rec is None
+        self.kern.riccati_gain(self.A, self.Bm, *self.hessians(), self.K, self.Quu if full else None,
+                               self.fac if full else None, self.Qux if full else None,
                                Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active, rec=rec,
                                stream=_stream_ptr())
 
@@ -307,8 +311,11 @@ class Engine:
         """Marshal the argument block of isls_ilqr_admm_outer once; it stays valid while buffers are not re-allocated."""
         K = capi.Kernels
         rec = self.ff_record()
-        gain = K.gain_args(self.A, self.Bm, *self.hessians(), self.K, self.Quu, self.fac, self.Qux, Cux=self.Cux,
-                           solve_mode=self.solve_mode, status=self.status, active=self.admm_active, rec=rec)
+        # with the records, nothing in this driver reads Quu / fac / Qux: the gain pass then skips those stores
+        full = rec is None
+        gain = K.gain_args(self.A, self.Bm, *self.hessians(), self.K, self.Quu if full else None, self.fac if full else None,
+                           self.Qux if full else None, Cux=self.Cux, solve_mode=self.solve_mode, status=self.status,
+                           active=self.admm_active, rec=rec)
         ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                        Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
                        lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=self.ff_seg(ff_nseg), rec=rec)

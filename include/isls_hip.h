@@ -105,7 +105,7 @@ typedef struct isls_gain_args {
     isls_view Cxx;  /* [.,.,n,n] */
     isls_view Cuu;  /* [.,.,m,m] */
     isls_view Cux;  /* [.,.,m,n] ; p==NULL -> 0 */
-    void *K, *Quu, *fac, *Qux;
+    void *K, *Quu, *fac, *Qux; /* Quu, fac, Qux may all be NULL when `rec` is given (their consumers then read the records) */
     int32_t *status;       /* [B] OR-ed in */
     const int32_t *active; /* nullable */
     void *rec;             /* nullable: packed step records [A+B K | B | K | fac] (row-major blocks, RW = n*n+2*n*m+m*m words)
