@@ -204,6 +204,8 @@ def main():
         it_per_s = world * args.steps / dt
         w = 8
         abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti)
+        nseg_ff = max(1, int(eng._outer_args.ff.seg.nseg))
+        abytes[4] = abytes[4] * (nseg_ff - 1) / nseg_ff          # the operators cover every segment but the last
         sampled = len(range(0, args.steps, EVENT_PERIOD))
         dom = int(np.argmax([ms for ms, _ in fam]))
         default_workload = (B, N, J, L) == (4096, 100, 5, 20) and not args.lti
@@ -228,7 +230,14 @@ def main():
                          "traffic": pmc_traffic(dom) if default_workload else None,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": abytes[dom] * B,
                          "iteration_algorithmic_bytes": it_bytes,
-                         "iteration_frac": it_bytes * (it_per_s / world) / 1e9 / HBM_PEAK_GBS},
+                         "iteration_frac": it_bytes * (it_per_s / world) / 1e9 / HBM_PEAK_GBS,
+                         # every kernel family against the same HBM figure (algorithmic bytes / event-timed launch): the
+                         # rollout is issue bound, the feed-forward pass is the one that streams
+                         "families": {KIND_NAMES[k]: {"avg_launch_ms": fam[k][0] / max(1, fam[k][1]),
+                                                      "achieved": (abytes[k] * B / (fam[k][0] / max(1, fam[k][1]) * 1e-3) / 1e9
+                                                                   if fam[k][0] > 0 else 0.0),
+                                                      "frac": (abytes[k] * B / (fam[k][0] / max(1, fam[k][1]) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                               if fam[k][0] > 0 else 0.0)} for k in range(5)}},
             "kernels_ms_per_step": {KIND_NAMES[k]: fam[k][0] / sampled for k in range(5)},
             "launches_per_step": {KIND_NAMES[k]: fam[k][1] / sampled for k in range(5)},
             "event_sampled_steps": sampled,
