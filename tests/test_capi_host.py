@@ -35,7 +35,8 @@ def test_struct_layouts_match_header():
     """sizeof of every argument struct as compiled from the header by gcc == ctypes' layout."""
     import subprocess
     import tempfile
-    names = ["gain", "ff", "ff_prepare", "rollout", "admm", "project", "sls_admm", "expand", "linearize", "accept", "outer"]
+    names = ["gain", "ff", "ff_prepare", "rollout", "admm", "project", "sls_admm", "expand", "linearize", "accept", "outer",
+             "columns", "columns_admm", "dense_loop"]
     src = '#include <stdio.h>\n#include "isls_hip.h"\nint main(){' + "".join(
         f'printf("%zu\\n", sizeof(isls_{n}_args));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
@@ -43,8 +44,17 @@ def test_struct_layouts_match_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "s"), os.path.join(d, "s.c")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     structs = [capi.GainArgs, capi.FfArgs, capi.FfPrepareArgs, capi.RolloutArgs, capi.AdmmArgs, capi.ProjectArgs, capi.SlsAdmmArgs, capi.ExpandArgs, capi.LinearizeArgs,
-               capi.AcceptArgs, capi.OuterArgs]
+               capi.AcceptArgs, capi.OuterArgs, capi.ColumnsArgs, capi.ColumnsAdmmArgs, capi.DenseLoopArgs]
     assert sizes == [ctypes.sizeof(s) for s in structs]
+
+
+def test_record_buffer_size_matches_the_library():
+    """isls_ff_record_elems (the packed-record buffer is blocked by wavefront, so its size is padded to whole wavefronts)"""
+    lib = capi.load_hip_library()
+    lib.isls_ff_record_elems.restype = ctypes.c_int64
+    for B, N, n, m in ((1, 2, 2, 1), (7, 100, 6, 3), (8, 100, 6, 3), (4096, 100, 6, 3), (33, 40, 9, 3), (5, 200, 4, 2)):
+        got = lib.isls_ff_record_elems(ctypes.c_int32(B), ctypes.c_int32(N), ctypes.c_int32(n), ctypes.c_int32(m))
+        assert got == capi.ff_record_elems(B, N, n, m) >= B * N * (n * n + 2 * n * m + m * m)
 
 
 def test_make_view_strides():
