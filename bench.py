@@ -35,7 +35,14 @@ KIND_NAMES = ["riccati_gain_kernel", "riccati_ff_kernel", "rollout_kernel", "adm
 # kernels behind each timed family (isls_timing kind): the time-parallel feed-forward pass is two launches
 KIND_KERNELS = [["riccati_gain_kernel"], ["riccati_ff_kernel", "riccati_ffrec_kernel", "ff_stitch_kernel"], ["rollout_kernel"],
                 ["admm_update_kernel"], ["ff_prepare_kernel", "ff_prepare_rec_kernel"]]
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def _latest_pmc_file():
+    """Newest committed PMC traffic table (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return files[-1] if files else None
+
+
+PMC_FILE = _latest_pmc_file()
 
 
 def pmc_traffic(kind):
@@ -43,7 +50,7 @@ def pmc_traffic(kind):
     or None when no profile of this workload is available."""
     try:
         kernels = json.load(open(PMC_FILE))["kernels"]
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         return None
     total, found = 0.0, False
     for name, rec in kernels.items():
@@ -53,21 +60,49 @@ def pmc_traffic(kind):
     return total if found else None
 
 
-def algorithmic_bytes(n, m, N, w, has_x, has_u, lti):
-    """Compulsory HBM bytes per trajectory per launch of each kernel family (each distinct array once)."""
+def algorithmic_bytes(n, m, N, w, has_x, has_u, lti, hess_shared, records):
+    """HBM bytes per trajectory per launch that each kernel family MUST move in the layout in use (each distinct array
+    once; stride-0 shared tables cost nothing per trajectory):
+      hess_shared : Cxx, Cuu are batch-shared [N,.,.] tables (Engine._shared_hessian) -> not counted;
+      records     : the feed-forward passes read the packed step records [A+BK | B | K | fac] of the gain pass, so the
+                    gain pass does not write Quu / fac / Qux and ff reads n^2+2nm+m^2 words per step instead of the six
+                    arrays.  The records themselves are an internal layout: the gain pass is credited with A, B in and
+                    K out only (writing them is its own overhead), ff with what it reads."""
     ab = 0 if lti else n * n + n * m
+    hess = 0 if hess_shared else n * n + m * m
     reg = (3 * n if has_x else 0) + (3 * m if has_u else 0)            # xhat/uhat, z, lambda of the regularised blocks
-    gain = ab + n * n + m * m + (2 * m * n + 2 * m * m)               # A,B,Cxx,Cuu in; K,Qux,Quu,fac out
-    ff = ab + 2 * m * n + 2 * m * m + (n + m) + reg + m               # A,B,K,Qux,Quu,fac,c0,reg in; k out
+    gain = ab + hess + m * n + (0 if records else m * n + 2 * m * m)   # A,B,(Cxx,Cuu) in; K (,Qux,Quu,fac) out
+    ops = (n * n + 2 * n * m + m * m) if records else (ab + 2 * m * n + 2 * m * m)
+    ff = ops + (n + m) + reg + m                                       # operators, c0, reg in; k out
     ro = m * n + m + (n + m) + ((2 * n if has_x else 0) + (2 * m if has_u else 0)) + (n + m)   # K,k,nominal,z,l in; x,u out
     admm = (5 * n if has_x else 0) + (5 * m if has_u else 0)          # x,z,l in; z,l out
-    prep = ab + 2 * m * n + 2 * m * m + m * n                         # A,B,K,Qux,Quu,fac in; G out (once per gain pass)
+    prep = ops + m * n                                                 # operators in; G out (once per gain pass)
     return [w * N * v for v in (gain, ff, ro, admm, prep)]
 
 
-def iteration_bytes(n, m, N, w):
-    """SURVEY 8(d) official figure: bytes_traj = w*N*[2n^2 + 2nm + m^2 + m + 7(n+m)] (fully fused ideal)."""
-    return w * N * (2 * n * n + 2 * n * m + m * m + m + 7 * (n + m))
+def iteration_bytes(n, m, N, w, hess_shared):
+    """SURVEY 8(d) official figure: bytes_traj = w*N*[2n^2 + 2nm + m^2 + m + 7(n+m)] (fully fused ideal); the n^2 + m^2
+    of Cxx, Cuu are dropped when they are batch-shared tables ("drop the Cxx,Cuu terms when they are shared")."""
+    return w * N * (2 * n * n + 2 * n * m + m * m + m + 7 * (n + m) - (n * n + m * m if hess_shared else 0))
+
+
+def spawn_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks (one per GPU, RCCL) as a
+    CHILD process and return its exit code.  Called before anything initialises the GPU; device_count() does not."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        sys.exit(f"bench.py: --gpus {n_gpus} requested but only {have} HIP device(s) are visible; refusing to print a "
+                 f"{n_gpus}-GPU line from fewer devices")
+    with socket.socket() as so:                                # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -91,9 +126,17 @@ def main():
     if args.isls_admm:
         return isls_admm_main(args)
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)                         # child launcher; nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
+        sys.exit(f"bench.py: rank {rank} needs device {local_rank}, only {torch.cuda.device_count()} HIP device(s) visible")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -107,7 +150,7 @@ def main():
     import isls_problems as P
     from isls import _capi as capi
     from isls.engine import Engine, library
-    from isls.shard import allreduce_convergence
+    from isls.shard import allreduce_table
 
     B, N, J, L = args.batch, args.horizon, args.J, args.L
     cfg = P.config2(batch=B, N=N, seed=rank)
@@ -133,8 +176,8 @@ def main():
         eng.expand()                                          # Cxx,Cuu,c0x,c0u about the nominal
         eng.run_outer()                                       # gain + J x (ff, rollout, update), one C call
         eng.accept_x_step()                                   # nominal <- x-step, cost log (no stop rule)
-        eng.reduce()
-        allreduce_convergence(eng.out5, rank, world, buf=red)  # the one collective: 5 doubles per rank (RCCL)
+        eng.reduce(table=red, rank=rank)                      # this shard's row of the [W,5] table, one launch
+        allreduce_table(red, world)                           # the one collective: 5 doubles per rank (RCCL)
 
     lib = library()
     for _ in range(args.warmup):
@@ -142,18 +185,20 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    lib.isls_timing_enable(1)
+    timing = lib.isls_timing_create()                        # caller-owned event context, handed to the C driver
+    eng._outer_args.timing = timing
+    lib.isls_timing_reset(timing)
     t0 = time.perf_counter()
     for i in range(args.steps):
         # per-launch HIP events on every EVENT_PERIOD-th step of the timed region: an event pair per launch costs a
         # few microseconds of queue bubbles (measured: 2.03 ms per step with events on every step, 1.89 without)
-        lib.isls_timing_pause(0 if i % EVENT_PERIOD == 0 else 1)
+        lib.isls_timing_pause(timing, 0 if i % EVENT_PERIOD == 0 else 1)
         step()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    lib.isls_timing_enable(0)
+    eng._outer_args.timing = None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -173,8 +218,8 @@ def main():
             eng.expand()
             eng.run_outer()
             eng.accept_x_step()
-            eng.reduce()
-            allreduce_convergence(eng.out5, rank, world, buf=red)
+            eng.reduce(table=red, rank=rank)
+            allreduce_table(red, world)
 
         step_lti()
         if dist is not None:
@@ -197,13 +242,15 @@ def main():
     fam = []
     for kind in range(5):
         cnt = ctypes.c_int(0)
-        ms = lib.isls_timing_read_ms(kind, ctypes.byref(cnt))
+        ms = lib.isls_timing_read_ms(timing, kind, ctypes.byref(cnt))
         fam.append((ms, cnt.value))
+    lib.isls_timing_destroy(timing)
 
     if rank == 0:
         it_per_s = world * args.steps / dt
         w = 8
-        abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti)
+        records = eng.ff_record() is not None
+        abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti, hess_shared=hess_shared, records=records)
         nseg_ff = max(1, int(eng._outer_args.ff.seg.nseg))
         abytes[4] = abytes[4] * (nseg_ff - 1) / nseg_ff          # the operators cover every segment but the last
         sampled = len(range(0, args.steps, EVENT_PERIOD))
@@ -211,7 +258,17 @@ def main():
         default_workload = (B, N, J, L) == (4096, 100, 5, 20) and not args.lti
         avg_ms = fam[dom][0] / max(1, fam[dom][1])
         achieved = abytes[dom] * B / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        it_bytes = iteration_bytes(n, m, N, w) * B
+        it_bytes = iteration_bytes(n, m, N, w, hess_shared) * B
+        # every kernel family against the same HBM figure (algorithmic bytes / event-timed launch) with the PMC-measured
+        # traffic of the committed profile next to it: the rollout is issue bound, the feed-forward pass is the one that streams
+        families = {}
+        for k in range(5):
+            avg = fam[k][0] / max(1, fam[k][1])
+            ach = abytes[k] * B / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            pmc = pmc_traffic(k) if default_workload else None
+            families[KIND_NAMES[k]] = {"avg_launch_ms": avg, "algorithmic_bytes_per_launch": abytes[k] * B, "achieved": ach,
+                                       "frac": ach / HBM_PEAK_GBS, "pmc_bytes": pmc,
+                                       "pmc_over_algorithmic": (pmc / (abytes[k] * B) if pmc and abytes[k] else None)}
         out = {
             "metric": "iLQR-ADMM iterations/sec, batch=4096 N=100 x_dim=6",
             "value": it_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -233,11 +290,8 @@ def main():
                          "iteration_frac": it_bytes * (it_per_s / world) / 1e9 / HBM_PEAK_GBS,
                          # every kernel family against the same HBM figure (algorithmic bytes / event-timed launch): the
                          # rollout is issue bound, the feed-forward pass is the one that streams
-                         "families": {KIND_NAMES[k]: {"avg_launch_ms": fam[k][0] / max(1, fam[k][1]),
-                                                      "achieved": (abytes[k] * B / (fam[k][0] / max(1, fam[k][1]) * 1e-3) / 1e9
-                                                                   if fam[k][0] > 0 else 0.0),
-                                                      "frac": (abytes[k] * B / (fam[k][0] / max(1, fam[k][1]) * 1e-3) / 1e9 / HBM_PEAK_GBS
-                                                               if fam[k][0] > 0 else 0.0)} for k in range(5)}},
+                         "pmc_profile": os.path.basename(PMC_FILE) if (PMC_FILE and default_workload) else None,
+                         "families": families},
             "kernels_ms_per_step": {KIND_NAMES[k]: fam[k][0] / sampled for k in range(5)},
             "launches_per_step": {KIND_NAMES[k]: fam[k][1] / sampled for k in range(5)},
             "event_sampled_steps": sampled,
@@ -428,4 +482,4 @@ def cpu_baseline(cfg, args, B, N, n, m, J, L):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -1,5 +1,6 @@
 // capi.hip -- extern "C" surface of libisls_hip.so (declared in include/isls_hip.h) and the
 // stream-ordered driver of one outer DP-form iLQR-ADMM iteration.
+#include <new>
 #include <vector>
 
 #include "isls_common.hpp"
@@ -7,29 +8,28 @@
 namespace isls {
 
 // ---- optional per-kernel-family timing with HIP events on the launch stream -----------------------
-// (bench.py reads these: average launch duration of the dominant kernel for the roofline line)
+// (bench.py reads these: average launch duration of the dominant kernel for the roofline line).  The context is
+// caller-owned (isls_timing_create / isls_timing_destroy) and reaches the driver through isls_outer_args.timing: the
+// library itself keeps no state.  One context belongs to one host thread / stream at a time.
 struct Timing {
-    bool on = false;
-    bool paused = false;           // events are recorded only while on && !paused (bench.py samples every k-th step)
+    bool paused = false;           // events are recorded only while !paused (bench.py samples every k-th step)
     static constexpr int kKinds = 5;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[kKinds];
     size_t used[kKinds] = {0, 0, 0, 0, 0};
 };
-static Timing g_timing;
 
 struct ScopedTimer {
-    int kind;
     hipStream_t s;
     hipEvent_t stop = nullptr;
-    ScopedTimer(int kind_, hipStream_t s_) : kind(kind_), s(s_)
+    ScopedTimer(Timing *tm, int kind, hipStream_t s_) : s(s_)
     {
-        if (!g_timing.on || g_timing.paused) return;
-        auto &pool = g_timing.ev[kind];
-        size_t &u = g_timing.used[kind];
+        if (!tm || tm->paused) return;
+        auto &pool = tm->ev[kind];
+        size_t &u = tm->used[kind];
         if (u == pool.size()) {
             hipEvent_t a, b;
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+            if (hipEventCreate(&a) != hipSuccess) return;
+            if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return; }
             pool.emplace_back(a, b);
         }
         hipEventRecord(pool[u].first, s);
@@ -46,11 +46,12 @@ template <typename T>
 static int outer_iteration(const isls_outer_args &a, hipStream_t s)
 {
     const isls_admm_args &ad = a.admm;
+    Timing *const tmg = static_cast<Timing *>(a.timing);
     int rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, ad.iters, s);
     if (rc != ISLS_OK) return rc;
     if (!a.skip_gain) {
         {
-            ScopedTimer tm(0, s);
+            ScopedTimer tm(tmg, 0, s);
             if ((rc = launch_gain<T>(a.gain, s)) != ISLS_OK) return rc;
         }
         if (ff_seg_enabled(a.ff.seg)) {                        // operators of the time-parallel feed-forward pass
@@ -59,7 +60,7 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
             pr.B = f.B; pr.N = f.N; pr.n = f.n; pr.m = f.m; pr.solve_mode = f.solve_mode;
             pr.A = f.A; pr.Bm = f.Bm; pr.K = f.K; pr.Quu = f.Quu; pr.fac = f.fac; pr.Qux = f.Qux;
             pr.active = f.active; pr.seg = f.seg; pr.rec = f.rec;
-            ScopedTimer tm(4, s);
+            ScopedTimer tm(tmg, 4, s);
             if ((rc = launch_ff_prepare<T>(pr, s)) != ISLS_OK) return rc;
         }
     }
@@ -68,15 +69,15 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
     bool fused = false;
     for (int j = 0; j < a.J; ++j) {
         {
-            ScopedTimer tm(1, s);
+            ScopedTimer tm(tmg, 1, s);
             if ((rc = launch_ff<T>(a.ff, s)) != ISLS_OK) return rc;
         }
         {
-            ScopedTimer tm(2, s);
+            ScopedTimer tm(tmg, 2, s);
             if ((rc = launch_rollout<T>(a.ro, s, fuse ? &a.admm : nullptr, &fused)) != ISLS_OK) return rc;
         }
         if (!fused) {
-            ScopedTimer tm(3, s);
+            ScopedTimer tm(tmg, 3, s);
             if ((rc = launch_admm<T>(a.admm, s)) != ISLS_OK) return rc;
         }
         if (a.log) {
@@ -99,14 +100,12 @@ using namespace isls;
     {                                                                                      \
         if (!a) return ISLS_ERR_ARG;                                                       \
         if (a->B == 0) return ISLS_OK; /* empty batch: nothing to check, nothing to do */  \
-        ScopedTimer tm(kind, (hipStream_t)stream);                                         \
         return launcher<double>(*a, (hipStream_t)stream);                                  \
     }                                                                                      \
     ISLS_API int isls_##name##_f32(const args_t *a, void *stream)                          \
     {                                                                                      \
         if (!a) return ISLS_ERR_ARG;                                                       \
         if (a->B == 0) return ISLS_OK;                                                     \
-        ScopedTimer tm(kind, (hipStream_t)stream);                                         \
         return launcher<float>(*a, (hipStream_t)stream);                                   \
     }
 
@@ -206,6 +205,18 @@ ISLS_API int isls_reduce_convergence_f32(int32_t B, const void *cost, const void
 {
     return launch_reduce<float>(B, cost, res, active, status, out5, (hipStream_t)stream);
 }
+ISLS_API int isls_reduce_convergence_table_f64(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                               const int32_t *status, void *table, int32_t rank, int32_t world, void *stream)
+{
+    if (rank < 0) return ISLS_ERR_ARG;
+    return launch_reduce<double>(B, cost, res, active, status, table, (hipStream_t)stream, rank, world);
+}
+ISLS_API int isls_reduce_convergence_table_f32(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                               const int32_t *status, void *table, int32_t rank, int32_t world, void *stream)
+{
+    if (rank < 0) return ISLS_ERR_ARG;
+    return launch_reduce<float>(B, cost, res, active, status, table, (hipStream_t)stream, rank, world);
+}
 ISLS_API int isls_ilqr_admm_outer_f64(const isls_outer_args *a, void *stream)
 {
     return a ? outer_iteration<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
@@ -243,34 +254,52 @@ ISLS_API const char *isls_error_string(int code)
     }
 }
 
-ISLS_API int isls_timing_enable(int on)
+ISLS_API void *isls_timing_create(void) { return new (std::nothrow) Timing(); }
+
+ISLS_API void isls_timing_destroy(void *h)
 {
-    g_timing.on = on != 0;
-    g_timing.paused = false;
-    if (on)   // (re)start a measurement window; disabling keeps the recorded events readable
-        for (int k = 0; k < Timing::kKinds; ++k) g_timing.used[k] = 0;
-    return 0;
+    Timing *tm = static_cast<Timing *>(h);
+    if (!tm) return;
+    for (int k = 0; k < Timing::kKinds; ++k)
+        for (auto &pr : tm->ev[k]) {
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+    delete tm;
+}
+
+// Start a new measurement window (the recorded events of the previous one are reused).
+ISLS_API int isls_timing_reset(void *h)
+{
+    Timing *tm = static_cast<Timing *>(h);
+    if (!tm) return ISLS_ERR_ARG;
+    tm->paused = false;
+    for (int k = 0; k < Timing::kKinds; ++k) tm->used[k] = 0;
+    return ISLS_OK;
 }
 
 // Suspend / resume event recording inside a measurement window without resetting it (an event pair per launch
 // costs a few microseconds of queue bubbles; sampling every k-th step keeps the timed region representative).
-ISLS_API int isls_timing_pause(int paused)
+ISLS_API int isls_timing_pause(void *h, int paused)
 {
-    g_timing.paused = paused != 0;
-    return 0;
+    Timing *tm = static_cast<Timing *>(h);
+    if (!tm) return ISLS_ERR_ARG;
+    tm->paused = paused != 0;
+    return ISLS_OK;
 }
 
-// Sum of the event-bracketed durations of kernel family `kind` since isls_timing_enable(1); *count =
-// number of launches.  Synchronises on the recorded events (call it outside the timed region).
-ISLS_API double isls_timing_read_ms(int kind, int *count)
+// Sum of the event-bracketed durations of kernel family `kind` since isls_timing_reset(); *count = number of
+// launches.  Synchronises on the recorded events (call it outside the timed region).
+ISLS_API double isls_timing_read_ms(void *h, int kind, int *count)
 {
-    if (kind < 0 || kind >= Timing::kKinds) return -1.0;
+    Timing *tm = static_cast<Timing *>(h);
+    if (!tm || kind < 0 || kind >= Timing::kKinds) return -1.0;
     double total = 0.0;
-    const size_t n = g_timing.used[kind];
+    const size_t n = tm->used[kind];
     for (size_t i = 0; i < n; ++i) {
         float ms = 0.f;
-        hipEventSynchronize(g_timing.ev[kind][i].second);
-        if (hipEventElapsedTime(&ms, g_timing.ev[kind][i].first, g_timing.ev[kind][i].second) == hipSuccess) total += ms;
+        hipEventSynchronize(tm->ev[kind][i].second);
+        if (hipEventElapsedTime(&ms, tm->ev[kind][i].first, tm->ev[kind][i].second) == hipSuccess) total += ms;
     }
     if (count) *count = (int)n;
     return total;

@@ -357,8 +357,14 @@ template int launch_accept<float>(const isls_accept_args &, hipStream_t);
 // out5 = { sum cost, max prim, max dual, #active, #status!=0 } over the local shard (single workgroup)
 template <typename T>
 __global__ __launch_bounds__(1024) void reduce_kernel(int B, const T *cost, const T *res, const int32_t *active,
-                                                     const int32_t *status, T *out5)
+                                                     const int32_t *status, T *out5, int row, int rows)
 {
+    // table form (row >= 0): out5 is a [rows,5] table, this shard's numbers go to `row`, the other rows are zeroed
+    if (row >= 0) {
+        for (int e = threadIdx.x; e < rows * 5; e += blockDim.x)
+            if (e / 5 != row) out5[e] = T(0);
+        out5 += row * 5;
+    }
     __shared__ T sm[5][16];                                   // one partial per wavefront of the 1024-thread workgroup
     T cs = T(0), pm = T(0), dm = T(0), na = T(0), nf = T(0);
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
@@ -384,16 +390,16 @@ __global__ __launch_bounds__(1024) void reduce_kernel(int B, const T *cost, cons
 
 template <typename T>
 int launch_reduce(int32_t B, const void *cost, const void *res, const int32_t *active, const int32_t *status,
-                  void *out5, hipStream_t s)
+                  void *out5, hipStream_t s, int row, int rows)
 {
-    if (B < 0 || !out5) return ISLS_ERR_ARG;
+    if (B < 0 || !out5 || (row >= 0 && (rows < 1 || row >= rows))) return ISLS_ERR_ARG;
     // latency-bound (5 small loads per trajectory): the widest workgroup keeps the dependent iterations short
     hipLaunchKernelGGL((reduce_kernel<T>), dim3(1), dim3(B > 256 ? 1024 : 256), 0, s, (int)B, (const T *)cost, (const T *)res, active,
-                       status, (T *)out5);
+                       status, (T *)out5, row, rows);
     return check_launch();
 }
-template int launch_reduce<double>(int32_t, const void *, const void *, const int32_t *, const int32_t *, void *, hipStream_t);
-template int launch_reduce<float>(int32_t, const void *, const void *, const int32_t *, const int32_t *, void *, hipStream_t);
+template int launch_reduce<double>(int32_t, const void *, const void *, const int32_t *, const int32_t *, void *, hipStream_t, int, int);
+template int launch_reduce<float>(int32_t, const void *, const void *, const int32_t *, const int32_t *, void *, hipStream_t, int, int);
 
 // ------------------------------------------------------------------------------------------------
 // start of an outer iteration: admm_active <- outer_active, lambda <- 0 (isls.py:414-415,482),

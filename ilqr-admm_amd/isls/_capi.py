@@ -17,7 +17,7 @@ try:  # torch is plumbing (device memory, streams); the binding itself works on 
 except Exception:  # pragma: no cover
     torch = None
 
-ABI_VERSION = 101            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
+ABI_VERSION = 102            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
@@ -168,15 +168,16 @@ class ColumnsAdmmArgs(C.Structure):
 
 class OuterArgs(C.Structure):
     _fields_ = [("gain", GainArgs), ("ff", FfArgs), ("ro", RolloutArgs), ("admm", AdmmArgs),
-                ("J", C.c_int32), ("skip_gain", C.c_int32), ("log", C.c_void_p), ("outer_active", C.c_void_p)]
+                ("J", C.c_int32), ("skip_gain", C.c_int32), ("log", C.c_void_p), ("outer_active", C.c_void_p),
+                ("timing", C.c_void_p)]
 
 
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
-             "accept_step", "reduce_convergence", "ilqr_admm_outer")] + \
-           ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_error_string", "isls_timing_enable", "isls_timing_pause",
-            "isls_timing_read_ms"]
+             "accept_step", "reduce_convergence", "reduce_convergence_table", "ilqr_admm_outer")] + \
+           ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_error_string", "isls_timing_create",
+            "isls_timing_destroy", "isls_timing_reset", "isls_timing_pause", "isls_timing_read_ms"]
 
 
 SET_BOX, SET_SOC_UNIT, SET_SQUARE, SET_LINEAR, SET_QUADRATIC = 1, 2, 3, 4, 5
@@ -199,8 +200,13 @@ def load_hip_library(path=None):
         raise IslsError(f"{path} reports ABI version {lib.isls_version()}, this binding is for {ABI_VERSION}: rebuild it "
                         f"(`python __graft_entry__.py`)")
     lib.isls_error_string.restype = C.c_char_p
+    lib.isls_timing_create.restype = C.c_void_p
+    lib.isls_timing_destroy.restype = None
+    lib.isls_timing_destroy.argtypes = [C.c_void_p]
+    lib.isls_timing_reset.argtypes = [C.c_void_p]
+    lib.isls_timing_pause.argtypes = [C.c_void_p, C.c_int]
     lib.isls_timing_read_ms.restype = C.c_double
-    lib.isls_timing_read_ms.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    lib.isls_timing_read_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     return lib
 
 
@@ -643,6 +649,22 @@ class Kernels:
         rc = fn(*argv)
         if rc != OK:
             raise IslsError(f"reduce_convergence -> {rc}")
+        return rc
+
+    def reduce_convergence_table(self, cost, res, active, status, table, rank, stream=None):
+        """isls_reduce_convergence_table: the shard's five numbers into row `rank` of the [W,5] table, other rows zeroed."""
+        world = int(table.shape[0])
+        _dense(table, (world, 5), "table")
+        fn = getattr(self.lib, f"{self.prefix}reduce_convergence_table_{_sfx(table)}")
+        fn.restype = C.c_int
+        B = int(cost.shape[0]) if cost is not None else int(res.shape[0])
+        argv = [C.c_int32(B), C.c_void_p(_ptr(cost)), C.c_void_p(_ptr(res)), C.c_void_p(_ptr(active)),
+                C.c_void_p(_ptr(status)), C.c_void_p(_ptr(table)), C.c_int32(int(rank)), C.c_int32(world)]
+        if self.with_stream:
+            argv.append(C.c_void_p(stream or 0))
+        rc = fn(*argv)
+        if rc != OK:
+            raise IslsError(f"reduce_convergence_table -> {rc}")
         return rc
 
     def outer(self, gain, ff, ro, admm, J, sfx, skip_gain=False, log=None, outer_active=None, stream=None):

@@ -350,7 +350,12 @@ class Engine:
                               cost_hist=self.cost_hist, hist_len=self.hist_len, tol_cost=tol_cost, tol_osc=tol_osc,
                               outer_active=self.outer_active, stream=_stream_ptr())
 
-    def reduce(self):
-        """[sum cost, max prim, max dual, #active, #failed] of the local shard, left on the device."""
+    def reduce(self, table=None, rank=0):
+        """[sum cost, max prim, max dual, #active, #failed] of the local shard, left on the device: in `out5`, or straight
+        in row `rank` of the all-reduce's [W,5] `table` (its other rows zeroed) -- one launch either way."""
+        if table is not None:
+            self.kern.reduce_convergence_table(self.cost, self.res, self.outer_active, self.status, table, rank,
+                                               stream=_stream_ptr())
+            return table
         self.kern.reduce_convergence(self.cost, self.res, self.outer_active, self.status, self.out5, stream=_stream_ptr())
         return self.out5

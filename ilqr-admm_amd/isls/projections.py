@@ -295,8 +295,8 @@ def _consensus_residual_loop(update, max_iter, threshold, rel=1e-5):
 def project_set_convex(x0, As=[], bs=[], projections=[], rho=1, max_iter=200, threshold=1e-4, verbose=False):
     """Projection onto the intersection {x : A_i x + b_i in C_i} by consensus ADMM (isls/projections.py:289-374):
     x = (I + rho sum A_i'A_i)^-1 (x0 + rho sum A_i'(z_i - b_i - lmb_i)); z_i = P_i(A_i x + b_i + lmb_i); lmb_i += A_i x + b_i - z_i."""
-    single = x0.ndim == 1
-    X0 = (x0[None] if single else x0).T
+    X0 = (x0[None] if x0.ndim == 1 else x0).T
+    single = X0.shape[1] == 1                 # the reference squeezes whenever nb_size == 1, also for a [1, d] input (projections.py:371-374)
     x = X0.copy()
     z = [A @ x + b[:, None] for A, b in zip(As, bs)]
     lmb = [np.zeros_like(zi) for zi in z]

@@ -29,3 +29,18 @@ def allreduce_convergence(out5, rank, world, group=None, buf=None):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     total = torch.stack([buf[:, 0].sum(), buf[:, 1].max(), buf[:, 2].max(), buf[:, 3].sum(), buf[:, 4].sum()])
     return total, buf
+
+
+def allreduce_table(table, world, group=None):
+    """The collective of an outer iteration on a [W,5] table whose row `rank` this shard has just filled and whose other
+    rows are zero (`Engine.reduce(table=..., rank=...)` writes it that way in one launch): ONE in-place sum-all-reduce,
+    nothing else on the stream.  With world == 1 there is nothing to exchange."""
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    return table
+
+
+def summarize(table):
+    """[sum cost, max prim, max dual, #active, #failed] of the whole batch from the gathered [W,5] table."""
+    return torch.stack([table[:, 0].sum(), table[:, 1].max(), table[:, 2].max(), table[:, 3].sum(), table[:, 4].sum()])

@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer into caller-owned memory (torch tensors in our host code);
- *     the library allocates nothing, keeps no global state, and is re-entrant per stream;
+ *     the library allocates no device memory, keeps no global state, and is re-entrant per stream
+ *     (tuning overrides read from the environment, ISLS_*_TPW / ISLS_FF_*, are the one process-wide input);
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return value: ISLS_OK or a negative ISLS_ERR_* (argument / unsupported-size / launch error);
  *     numerical trouble is reported per trajectory in the int32 `status[B]` bit mask instead;
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ISLS_VERSION 101   /* 101: isls_gain_args.rec / isls_ff_args.rec, isls_columns_*, isls_dense_closed_loop_* */
+#define ISLS_VERSION 102   /* 102: caller-owned timing context (isls_outer_args.timing), isls_reduce_convergence_table_* */
 
 #define ISLS_OK 0
 #define ISLS_ERR_ARG (-1)
@@ -518,6 +519,12 @@ int isls_reduce_convergence_f64(int32_t B, const void *cost, const void *res, co
                                 const int32_t *status, void *out5, void *stream);
 int isls_reduce_convergence_f32(int32_t B, const void *cost, const void *res, const int32_t *active,
                                 const int32_t *status, void *out5, void *stream);
+/* The same reduction written straight into the [W,5] table of the all-reduce: row `rank` receives the five numbers, the
+ * other W-1 rows are zeroed (so that one sum-all-reduce of the table gathers every rank's row; isls/shard.py). */
+int isls_reduce_convergence_table_f64(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                      const int32_t *status, void *table, int32_t rank, int32_t world, void *stream);
+int isls_reduce_convergence_table_f32(int32_t B, const void *cost, const void *res, const int32_t *active,
+                                      const int32_t *status, void *table, int32_t rank, int32_t world, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One outer DP-form iLQR-ADMM iteration enqueued as a whole (SURVEY 3.3 with the dense solve
@@ -537,6 +544,7 @@ typedef struct isls_outer_args {
                                  * when the gain pass runs and ff.seg is set, the ff operators are prepared too */
     void *log;
     const int32_t *outer_active;
+    void *timing;               /* nullable: isls_timing_create() context that records the kernel-family durations */
 } isls_outer_args;
 
 int isls_ilqr_admm_outer_f64(const isls_outer_args *a, void *stream);
@@ -544,12 +552,15 @@ int isls_ilqr_admm_outer_f32(const isls_outer_args *a, void *stream);
 
 int isls_version(void);
 const char *isls_error_string(int code);
-/* name + duration bookkeeping used by bench.py: records hipEvents around the launches of one
- * kernel family on `stream`. kind: 0 gain, 1 ff, 2 rollout, 3 admm, 4 ff_prepare.  Returns ms of the last
- * completed timed launch set, or <0 if timing is disabled. */
-int isls_timing_enable(int on);
-int isls_timing_pause(int paused);   /* suspend / resume recording without resetting the window */
-double isls_timing_read_ms(int kind, int *count);
+/* Per-kernel-family durations for bench.py: HIP events recorded on the launch stream around the launches that
+ * isls_ilqr_admm_outer_* enqueues, kept in a CALLER-OWNED context (the library itself has no state): create one, put it
+ * into isls_outer_args.timing, read it after the timed region, destroy it.  kind: 0 gain, 1 ff, 2 rollout, 3 admm,
+ * 4 ff_prepare.  A context serves one host thread at a time. */
+void *isls_timing_create(void);
+void isls_timing_destroy(void *timing);
+int isls_timing_reset(void *timing);                 /* start a new measurement window                          */
+int isls_timing_pause(void *timing, int paused);     /* suspend / resume recording without resetting the window */
+double isls_timing_read_ms(void *timing, int kind, int *count);   /* summed ms and launch count of one family; synchronises */
 
 #ifdef __cplusplus
 }

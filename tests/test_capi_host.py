@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(capi.EXPORTED) == names                      # the binding knows exactly the header's surface
     lib.isls_version.restype = ctypes.c_int
-    assert lib.isls_version() == capi.ABI_VERSION == 101
+    assert lib.isls_version() == capi.ABI_VERSION == 102
     assert b"unsupported" in lib.isls_error_string(capi.ERR_UNSUPPORTED)
 
 
@@ -147,3 +147,31 @@ def test_two_rank_sharding_matches_single_process(oracle):
         assert table.shape == (world, 5)
         assert abs(total[0] - full[0]) < 1e-9 * max(1.0, abs(full[0]))
         assert np.allclose(total[1:], full[1:], rtol=1e-15, atol=0)
+
+
+def test_timing_context_is_caller_owned():
+    """isls_timing_*: create / reset / pause / read / destroy on a handle; nothing is recorded without launches, a NULL handle
+    is rejected (the library keeps no timing state of its own)."""
+    lib = capi.load_hip_library()
+    h = lib.isls_timing_create()
+    assert h
+    assert lib.isls_timing_reset(h) == capi.OK and lib.isls_timing_pause(h, 1) == capi.OK
+    cnt = ctypes.c_int(-1)
+    assert lib.isls_timing_read_ms(h, 2, ctypes.byref(cnt)) == 0.0 and cnt.value == 0
+    assert lib.isls_timing_read_ms(h, 9, ctypes.byref(cnt)) < 0
+    assert lib.isls_timing_reset(None) == capi.ERR_ARG and lib.isls_timing_read_ms(None, 0, None) < 0
+    lib.isls_timing_destroy(h)
+    assert ctypes.sizeof(capi.OuterArgs) % 8 == 0 and capi.OuterArgs.timing.offset == ctypes.sizeof(capi.OuterArgs) - 8
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """`python bench.py --gpus N` must never print an N-GPU line from fewer devices: without N visible HIP devices (none at
+    all in the build container) it exits non-zero with a message, before touching a GPU."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "--gpus 64" in r.stderr and "device" in r.stderr
+    assert not r.stdout.strip()
