@@ -237,7 +237,7 @@ ISLS_API int32_t isls_ff_segments(int32_t N, int32_t nseg_requested, int32_t *se
 ISLS_API int64_t isls_ff_record_elems(int32_t B, int32_t N, int32_t n, int32_t m)
 {
     if (B < 0 || N < 1 || n < 1 || m < 1 || n + m > kWave) return 0;
-    const int64_t tpw = kWave / (n + m), rw = (int64_t)n * n + 2 * n * m + m * m;
+    const int64_t tpw = kWave / (n + m), rw = rec_stride(n, m);
     return ((B + tpw - 1) / tpw) * tpw * N * rw;
 }
 

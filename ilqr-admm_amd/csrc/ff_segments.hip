@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64) void ff_prepare_rec_kernel(FfPrepP<T> p)
 {
     constexpr int GP = NX, MAXTPW = kWave / GP, TR = kWave / (NX + NU);
     constexpr int PHI_OFF = 0, B_OFF = NX * NX, FAC_OFF = B_OFF + NX * NU + NU * NX, RW = FAC_OFF + NU * NU, DUMP_OFF = RW;
+    constexpr int RS = rec_stride(NX, NU);                     // words between the records of consecutive trajectories
     constexpr int RECP = ((DUMP_OFF + 1) | 1), JR = (RW + GP - 1) / GP;
     __shared__ T lds[MAXTPW * 2 * RECP];
 
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64) void ff_prepare_rec_kernel(FfPrepP<T> p)
     const int t_first = sg * SL + SL - 1;                      // steps t_first, t_first-1, .. sg*SL
     const int jl = extra ? 0 : j;
     T *recs = lds + s * 2 * RECP;
-    const T *base = p.rec + (((int64_t)(b / TR) * N + t_first) * TR + (b % TR)) * RW;    // record (b, t_first); t-1 is TR*RW below
+    const T *base = p.rec + (((int64_t)(b / TR) * N + t_first) * TR + (b % TR)) * RS;    // record (b, t_first); t-1 is TR*RS below
     int off[JR], dst[JR];
 #pragma unroll
     for (int a = 0; a < JR; ++a) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64) void ff_prepare_rec_kernel(FfPrepP<T> p)
     for (int d = 0; d < D; ++d) {
         const int it = d < SL ? d : SL - 1;
 #pragma unroll
-        for (int a = 0; a < JR; ++a) rr[d][a] = base[off[a] - (int64_t)it * (TR * RW)];
+        for (int a = 0; a < JR; ++a) rr[d][a] = base[off[a] - (int64_t)it * (TR * RS)];
     }
     T psi[NX];
 #pragma unroll
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(64) void ff_prepare_rec_kernel(FfPrepP<T> p)
             {
                 const int itn = it + D < SL ? it + D : SL - 1;  // refill (clamped, unconditional)
 #pragma unroll
-                for (int a = 0; a < JR; ++a) rr[d][a] = base[off[a] - (int64_t)itn * (TR * RW)];
+                for (int a = 0; a < JR; ++a) rr[d][a] = base[off[a] - (int64_t)itn * (TR * RS)];
             }
             T pn[NX], qu[NU], kap[NU];
 #pragma unroll

@@ -162,6 +162,11 @@ __device__ __forceinline__ float py_mod(float a, float b)
     return r;
 }
 
+// Words between the packed step records [A+BK | B | K | fac] of consecutive trajectories of a wavefront (isls_gain_args.rec):
+// the record padded to an even word count, so that the feed-forward pass fetches records as aligned 16-byte pairs that
+// never straddle two trajectories.
+__host__ __device__ constexpr int rec_stride(int n, int m) { return (n * n + 2 * n * m + m * m + 1) & ~1; }
+
 // Launch wrappers implemented one per .hip file; each returns ISLS_OK / ISLS_ERR_*.
 template <typename T> int launch_gain(const isls_gain_args &a, hipStream_t s);
 template <typename T> int launch_ff(const isls_ff_args &a, hipStream_t s);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     constexpr int DUMP_OFF = K_OFF + NU * NX;              // W words that absorb the LDS writes of lanes with nothing to publish
     constexpr int SLOT = ((DUMP_OFF + W) | 1);             // odd stride: slots start on different banks
     constexpr int JA = (NX * NX + G - 1) / G, JB = (NX * NU + G - 1) / G, JQ = (NU * W + G - 1) / G;
-    constexpr int RB = NX * NX, RK = RB + NX * NU, RFAC = RK + NU * NX, RW = RFAC + NU * NU;   // packed record, see riccati_ffrec.hip
+    constexpr int RB = NX * NX, RK = RB + NX * NU, RFAC = RK + NU * NX, RW = rec_stride(NX, NU);   // packed record (padded stride), see riccati_ffrec.hip
     __shared__ T lds[TPW * SLOT];
 
     const int lane = threadIdx.x;

@@ -49,11 +49,11 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, MAXTPW = kWave / G;
     // packed record (HBM and LDS): Phi[NX][NX] | B[NX][NU] | K[NU][NX] | fac[NU][NU]
-    constexpr int PHI_OFF = 0, B_OFF = PHI_OFF + NX * NX, K_OFF = B_OFF + NX * NU, FAC_OFF = K_OFF + NU * NX, RW = FAC_OFF + NU * NU;
-    // slot: record | d[W] | v[NX] | cu[NU] | qu[NU] | dump
-    constexpr int D_OFF = RW, V_OFF = D_OFF + W, CU_OFF = V_OFF + NX, QU_OFF = CU_OFF + NU, DUMP_OFF = QU_OFF + NU;
-    constexpr int SLOT = ((DUMP_OFF + 1) | 1);
-    __shared__ T lds[(MAXTPW + 1) * SLOT];                     // + one dump slot for the lanes beyond the last slot
+    constexpr int PHI_OFF = 0, B_OFF = PHI_OFF + NX * NX, K_OFF = B_OFF + NX * NU, FAC_OFF = K_OFF + NU * NX, RW = rec_stride(NX, NU);
+    // slot: record (padded to an even word count) | d[W] | v[NX] | cu[NU] | qu[NU] | dump pair
+    constexpr int D_OFF = RW, V_OFF = D_OFF + W, CU_OFF = V_OFF + NX, QU_OFF = CU_OFF + NU, DUMP_OFF = (QU_OFF + NU + 1) & ~1;
+    constexpr int SLOT = DUMP_OFF + 2;                         // even: every slot's record starts on a 16-byte boundary
+    __shared__ __align__(16) T lds[(MAXTPW + 1) * SLOT];       // + one dump slot for the lanes beyond the last slot
     const int TPW = p.tpw;
 
     const int lane = threadIdx.x;
@@ -74,17 +74,19 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
     const bool hasreg = xl ? hasx : hasu;
     const int b0 = blockIdx.x * TPW;
 
-    // ---- load plan: the records are blocked by wavefront, [block][t][slot][RW], so the MAXTPW records of a step are one
-    // contiguous run of MAXTPW*RW words: lane l fetches words l, l+64, ... (fully coalesced 512-byte requests) and drops
-    // word w into slot w / RW of the LDS (surplus words into a dump word)
-    constexpr int BW = MAXTPW * RW, JR = (BW + kWave - 1) / kWave;
+    // ---- load plan: the records are blocked by wavefront, [block][t][slot][RW] with RW even, so the MAXTPW records of a
+    // step are one contiguous, 16-byte aligned run of MAXTPW*RW words: lane l fetches the word PAIRS l, l+64, ... (fully
+    // coalesced 1-KB requests, half as many as with single words -- the pass is bound by the requests it can keep in
+    // flight) and drops pair w into slot w / RW of the LDS (surplus pairs into the dump pair)
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    constexpr int BW = MAXTPW * RW, NP = BW / 2, JR = (NP + kWave - 1) / kWave;
     const T *bR = p.rec + (int64_t)blockIdx.x * N * BW;
     uint32_t oR[JR];
     int dR[JR];
 #pragma unroll
     for (int j = 0; j < JR; ++j) {
-        const int w = lane + kWave * j;
-        oR[j] = (uint32_t)(w < BW ? w : BW - 1);
+        const int w = 2 * (lane + kWave * j);
+        oR[j] = (uint32_t)(w < BW ? w : BW - 2);
         dR[j] = w < BW ? (w / RW) * SLOT + (w % RW) : MAXTPW * SLOT + DUMP_OFF;
     }
     const T *pc0 = (xl ? p.c0x.at(b0 + sl, 0) + i : p.c0u.at(b0 + sl, 0) + iu);
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
     const int lim = xl ? NX : NU;
 
     struct Stage {
-        T rr[JR];
+        V2 rr[JR];
         T c0, hv, zv, lv, rrow[ROWC ? 1 : NX];
     };
     auto fetch_vec = [&](int t, Stage &g) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
     auto fetch = [&](int t, Stage &g) {
         const T *r = bR + (int64_t)t * BW;
 #pragma unroll
-        for (int j = 0; j < JR; ++j) g.rr[j] = r[oR[j]];
+        for (int j = 0; j < JR; ++j) g.rr[j] = *reinterpret_cast<const V2 *>(r + oR[j]);
         fetch_vec(t, g);
     };
     // cx_i / cu_i = c0 + 2 * (row of Qr/Rr) . d       (isls/sls.py:132-137; O2 of SURVEY 8c)
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
             Stage &g = ring[d];
             // (a) stage the record of step t (unconditional) and publish d_i = xhat_i - (z_i - lambda_i)
 #pragma unroll
-            for (int j = 0; j < JR; ++j) lds[dR[j]] = g.rr[j];
+            for (int j = 0; j < JR; ++j) *reinterpret_cast<V2 *>(lds + dR[j]) = g.rr[j];
             rec[D_OFF + i] = hasreg ? g.hv - (g.zv - g.lv) : T(0);
             const T c0_now = g.c0;
             T row_now[NX];
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
 template <typename T>
 int launch_ff_record(const isls_ff_args &a, hipStream_t s)
 {
-    if ((int64_t)a.N * (a.n * (a.n + 2 * a.m) + a.m * a.m) * 64 >= ((int64_t)1 << 31)) return ISLS_ERR_UNSUPPORTED;
+    if ((int64_t)a.N * rec_stride(a.n, a.m) * 64 >= ((int64_t)1 << 31)) return ISLS_ERR_UNSUPPORTED;
     FfRecP<T> p;
     p.B = a.B; p.N = a.N; p.mode = a.solve_mode;
     p.c0x = View<T>(a.c0x); p.c0u = View<T>(a.c0u); p.Qr = View<T>(a.Qr); p.Rr = View<T>(a.Rr);

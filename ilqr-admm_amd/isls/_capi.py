@@ -255,7 +255,7 @@ def _dense(x, shape, name):
 def ff_record_elems(B, N, n, m):
     """isls_ff_record_elems: elements of the packed-record buffer of the gain pass (blocked by wavefront)."""
     tpw = 64 // (n + m)
-    return -(-B // tpw) * tpw * N * (n * n + 2 * n * m + m * m)
+    return -(-B // tpw) * tpw * N * ((n * n + 2 * n * m + m * m + 1) & ~1)       # record stride padded to an even word count
 
 
 def _record(rec, B, N, n, m):
