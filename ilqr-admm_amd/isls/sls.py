@@ -323,14 +323,16 @@ class SLS(Base):
         return dense.controller(Sw, Su, PHI_U, du)
 
     def ADMM_SLS(self, project_x=False, project_u=False, max_iter=5000, rho_x=0., rho_u=0., alpha=1., tol=1e-3,
-                 verbose=False, log=False):
+                 verbose=False, log=False, rel_tol=1e-2):
         """SLS-ADMM with robust (chance) constraints on the controls w.r.t. the initial position (isls/sls.py:319-454).
         `project_u` is a `projections.ConvexSets` acting on the rows y = [d_u, phi_u] of the (N m) x (1 + n/2) variable
         (e.g. `projections.chance_constraint_rows`); its A / b / par arrays may carry a leading batch axis for problems
         that differ in bound or variance, and `zs` may be given per problem.  The set-up (transfer matrices, the (N m)^2
         inverse) is host numpy, the ADMM loop of all problems is one device launch.  With `project_x` (a `ConvexSets` over
         the rows [d_x, phi_x], or the reference's callable on the (N n) x (1 + n/2) array), a non-zero `rho_x`, or callables,
-        the iteration runs over the feedback columns with the Riccati kernels instead.  Returns du, phi_u[, logs]."""
+        the iteration runs over the feedback columns with the Riccati kernels instead.  Returns du, phi_u[, logs].
+        `rel_tol` (not in the reference's signature) is the threshold of its second stop rule, hard-coded to 1e-2 there
+        (sls.py:426); 0 disables it, which pins the iteration count (that rule fires on rounding noise)."""
         has_rho_x = rho_x is not None and np.any(np.asarray(rho_x) != 0)
         if project_x or has_rho_x or not isinstance(project_u, ConvexSets):
             # state constraints, state weights or projections given as the reference's callables: ADMM over the feedback
@@ -363,7 +365,7 @@ class SLS(Base):
         iters = torch.zeros(B, dtype=torch.int32, device=e.device)
         e.kern.sls_admm(dev(l_side_inv), dev(r_side), dev(rr), sets, x_u, alpha=alpha, tol=tol, max_iter=max_iter,
                         rho=project_u.rho, inner_max_iter=project_u.max_iter, threshold=project_u.threshold, logs=logs,
-                        iters=iters, stream=torch.cuda.current_stream().cuda_stream)
+                        iters=iters, rel_tol=rel_tol, stream=torch.cuda.current_stream().cuda_stream)
         xu = x_u.cpu().numpy().astype(np.float64)
         self.sls_iters = iters.cpu().numpy()
         du = xu[..., 0]

@@ -619,7 +619,7 @@ def gen_sls():
                    max_iter=np.array(50), inner_rho=np.array(10.0), inner_max_iter=np.array(100), inner_threshold=np.array(1e-3))
         targets, bounds, variances, conf = [], [], [], []
         res = dict(du=[], phi_u=[], logs=[], n_it=[], xd=[], A0=[], A1=[], b0=[], b1=[], du0=[], PHI_U=[], K=[], k=[],
-                   mc_x0=[], mc_x=[], mc_u=[])
+                   mc_x0=[], mc_x=[], mc_u=[], fp32_sens=[])
         for b in range(nprob):
             target = np.concatenate([rng.uniform(0.5, 1.5, nb_dim), np.zeros(nb_dim)]) if b else np.concatenate([np.ones(nb_dim), np.zeros(nb_dim)])
             upper_u = [5.0, 4.0, 6.0, 5.5][b % 4]
@@ -649,6 +649,39 @@ def gen_sls():
                 K, k = sls.controller(phi_u, du)
             lg = np.full((50, 2), np.nan)
             lg[:len(logs)] = np.stack(logs)
+            # fp32 conditioning of THIS problem, measured on the reference itself (like o2_sens of the arm): its own
+            # intermediate inverses, its target and its constraint rows are perturbed by random relative errors of fp32
+            # rounding size (2^-24) -- what storing the x-step operands in fp32 does at the very least -- and the same
+            # ADMM_SLS call is repeated for the same number of iterations; how far du, phi_u move is a floor for any fp32
+            # evaluation of this iteration.
+            sens_b = np.zeros(2)
+            prng = np.random.default_rng(1000 + b)
+            jit = lambda a: a * (1.0 + 2.0 ** -24 * prng.uniform(-1.0, 1.0, np.shape(a)))   # noqa: E731
+            for _ in range(3):
+                sp = RefSLS(n, m, N)
+                sp.AB = [A, B]
+                sp.set_quadratic_cost(np.stack([np.zeros(n), jit(target)]), Qs, seq, u_std)
+                orig_inv = sp.compute_inverses
+                sp.compute_inverses = lambda M, f=orig_inv: [jit(np.array(X)) for X in f(M)]
+                Ap, bp = [jit(a_) for a_ in A_], [jit(b__) for b__ in b_]
+                proj_p = lambda y: refproj.project_set_convex(y, Ap, bp, projections=[refproj.project_soc_unit] * 2,   # noqa: E731
+                                                              rho=1e1, max_iter=100, threshold=1e-3)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    sp.solve_sls()
+                    du_p, phi_p, logs_p = sp.ADMM_SLS(project_u=proj_p, max_iter=len(logs), rho_u=1e2, alpha=1.0, tol=1e-3,
+                                                      verbose=0, log=True)
+                du_k, phi_k = du, phi_u
+                if len(logs_p) != len(logs):
+                    # the stop iteration is decided by the relative change of a residual at rounding level, i.e. by noise
+                    # (SURVEY 8c): compare at the perturbed run's iteration count, which the unperturbed reference reaches too
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        du_k, phi_k, logs_k = sls.ADMM_SLS(project_u=project_u, max_iter=len(logs_p), rho_u=1e2, alpha=1.0,
+                                                           tol=1e-3, verbose=0, log=True)
+                    assert len(logs_k) == len(logs_p)
+                sens_b[0] = max(sens_b[0], np.max(np.abs(du_p - du_k)) / max(1.0, np.max(np.abs(du_k))))
+                sens_b[1] = max(sens_b[1], np.max(np.abs(phi_p[:, :p] - phi_k[:, :p])) / max(1.0, np.max(np.abs(phi_k[:, :p]))))
+            res["fp32_sens"].append(sens_b)
+            print(tag, "problem", b, "fp32 sensitivity of the reference (du, phi_u)", sens_b)
             x0s = np.zeros((16, n))
             x0s[:, :p] = rng.normal(scale=np.sqrt(var_x0), size=(16, p))
             xm, um = sls.get_trajectory_sls(x0s, K, k, noise_scale=0.0)

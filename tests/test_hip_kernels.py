@@ -240,6 +240,38 @@ def test_fp32_kernels(dual, ff_record, ff_nseg):
     _report(dk)
 
 
+@pytest.mark.parametrize("which", ["arm", "car", "tassa"])
+def test_fp32_kernels_nonlinear_models(dual, golden, which):
+    """fp32 build of every kernel on the 3R arm (state + control boxes), the car (N = 200) and the Tassa car (pseudo-Huber
+    cost) against the fp32 oracle on identical inputs, kernel call by kernel call.  Tolerance: the north star's 1e-4, except
+    where the problem's own conditioning amplifies the last fp32 bit beyond that -- the arm carries weights of 1e6 next
+    to 1e-4 (its fp64 trace already moves by 8e-9 under 1e-15 perturbations, golden o2_sens): the same amplification of
+    fp32 rounding (6e-8) gives the bound used here."""
+    from helpers import tassa_arrays
+    f32 = np.float32
+    if which == "arm":
+        g = golden("g4_arm3r.npz")
+        amp = max(float(v) for v in g["o2_sens"]) / 1e-15            # measured amplification of a relative input perturbation
+        cfg = P.config3(batch=16, N=100, seed=0)
+        dk = dual(tol=max(1e-4, 10 * amp * 2.0 ** -24), ff_nseg=3, ff_record=True)
+        dk.int_exact = False
+        d = OracleDriver(dk, problem_arrays(cfg, range(5), dtype=f32), rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True, dtype=f32)
+        d.run(2, cfg["max_line_search"], 4, 0.0)
+    elif which == "car":
+        cfg = P.config4(batch=16, N=200, seed=0)
+        dk = dual(tol=1e-4, ff_nseg=4, ff_record=True)
+        dk.int_exact = False
+        d = OracleDriver(dk, problem_arrays(cfg, range(6), dtype=f32), rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True, dtype=f32)
+        d.run(2, 20, 3, 0.0)
+    else:
+        g = golden("g8_tassa.npz")
+        dk = dual(tol=1e-4, ff_nseg=3)
+        dk.int_exact = False
+        d = OracleDriver(dk, tassa_arrays(g, [0, 1], dtype=f32), rho_u=np.diag([1e-1, 1e-2]), dtype=f32)
+        d.run(2, 40, 3, 0.0)
+    _report(dk)
+
+
 def test_car_state_constraint_kernels(dual):
     """ISLS_PROJ_SETS inside the ADMM update (argument kernel + project_rows + update) on the car, kernel by kernel."""
     import sys
@@ -329,10 +361,11 @@ def test_projection_kernels(oracle, golden):
 @pytest.mark.parametrize("tag", ["d1", "d3"])
 def test_config5_sls_admm_kernels(oracle, golden, tag):
     """isls_sls_admm / isls_sls_closed_loop on the device against the oracle (fp64: every iteration, every problem) and
-    against the reference's golden outputs (fp64 and fp32: the metric's 1e-4)."""
+    against the reference's golden outputs: fp64 at 1e-7; fp32 (config 5's own precision) du, phi_u of EVERY problem at the
+    north star's 1e-4 or ten times the reference's measured fp32 sensitivity of that problem (fp32_tols), residual logs 2e-3."""
     import torch
     from dual import hip_kernels
-    from test_oracle_golden import _check_sls_admm, _run_sls_admm, _sls_case
+    from test_oracle_golden import _check_sls_admm, _run_sls_admm, _sls_case, fp32_tols
     g = golden(f"g7_sls_{tag}.npz")
     c = _sls_case(g)
     hip = hip_kernels()
@@ -348,7 +381,7 @@ def test_config5_sls_admm_kernels(oracle, golden, tag):
     # against the reference itself
     _check_sls_admm(lambda sel, mi, rt: host(_run_sls_admm(hip, c, g, wrap=dev, sel=sel, max_iter=mi, rel_tol=rt)), c, g, 1e-7)
     _check_sls_admm(lambda sel, mi, rt: host(_run_sls_admm(hip, c, g, dtype=np.float32, wrap=dev, sel=sel, max_iter=mi, rel_tol=rt)),
-                    c, g, 2e-3, only_converged=True)
+                    c, g, 2e-3, x_tols=fp32_tols(g))
     # closed-loop Monte-Carlo rollout with the reference's controller
     M = g["mc_x0"].shape[1]
     xl, ul = dev(np.zeros((M, c["N"], c["n"]))), dev(np.zeros((M, c["N"], c["m"])))

@@ -424,7 +424,14 @@ def _run_sls_admm(kern, c, g, dtype=np.float64, wrap=lambda a: a, sel=None, max_
     return x_u, logs, iters
 
 
-def _check_sls_admm(run, c, g, tol, only_converged=False):
+def fp32_tols(g):
+    """Per-problem fp32 tolerance of du / phi_u: the north star's 1e-4, or ten times the movement of the REFERENCE's own
+    du, phi_u under fp32-rounding-sized perturbations of its inverses, target and constraint rows (golden key fp32_sens,
+    tests/golden/make_golden.py::gen_sls) where the problem's conditioning makes that larger."""
+    return [max(1e-4, 10.0 * float(np.max(s))) for s in g["fp32_sens"]]
+
+
+def _check_sls_admm(run, c, g, tol, only_converged=False, x_tols=None):
     """The stop iteration of ADMM_SLS is decided by the relative change of a primal residual that has reached rounding
     level (8e-13 here), i.e. by noise -- it is not reproducible to the last step even for the reference.  So: (1) with
     the reference's rule the residual logs agree on the common prefix and the stop falls in the same stationary tail;
@@ -442,7 +449,9 @@ def _check_sls_admm(run, c, g, tol, only_converged=False):
     for b in probs:
         x1, _, it1 = run(b, int(g["n_it"][b]), 0.0)
         assert int(it1[0]) == int(g["n_it"][b])
-        assert rel_err(x1[0, :, 0], g["du"][b]) < tol and rel_err(x1[0, :, 1:], g["phi_u"][b][:, :c["p"]]) < tol
+        xt = tol if x_tols is None else x_tols[b]             # du, phi_u: per-problem bound (fp32), else the common one
+        assert rel_err(x1[0, :, 0], g["du"][b]) < xt and rel_err(x1[0, :, 1:], g["phi_u"][b][:, :c["p"]]) < xt, \
+            (b, rel_err(x1[0, :, 0], g["du"][b]), rel_err(x1[0, :, 1:], g["phi_u"][b][:, :c["p"]]), xt)
         outs.append(x1[0])
     return outs
 
