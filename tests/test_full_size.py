@@ -134,19 +134,25 @@ def test_config5_full_size_properties(nb_dim):
         x_u = torch.zeros(P_, r_side.shape[1], r_side.shape[2], dtype=torch.float32, device="cuda")
         z = torch.zeros_like(x_u)
         it = torch.zeros(P_, dtype=torch.int32, device="cuda")
+        logs = torch.full((P_, iters, 2), float("nan"), dtype=torch.float32, device="cuda")
         hip.sls_admm(dev(Linv), dev(r_side[sel]), dev(rr), sets, x_u, alpha=1.0, tol=1e-3, max_iter=iters, rho=cs.rho,
-                     inner_max_iter=cs.max_iter, threshold=cs.threshold, z=z, iters=it, rel_tol=1e-2)
+                     inner_max_iter=cs.max_iter, threshold=cs.threshold, z=z, iters=it, logs=logs, rel_tol=1e-2)
         torch.cuda.synchronize()
-        return x_u.cpu().numpy(), z.cpu().numpy(), it.cpu().numpy()
+        return x_u.cpu().numpy(), z.cpu().numpy(), it.cpu().numpy(), logs.cpu().numpy()
     allp = np.arange(B)
-    xu, z, it = run(allp)
+    xu, z, it, lg = run(allp)
     sel = np.array([0, 1, 4097, 8191, 5000, 77])
-    xu_s, z_s, it_s = run(sel)
+    xu_s, z_s, it_s, lg_s = run(sel)
     assert np.array_equal(xu[sel], xu_s) and np.array_equal(z[sel], z_s) and np.array_equal(it[sel], it_s)
+    assert np.array_equal(lg[sel], lg_s, equal_nan=True)
     assert np.all(it >= 1) and np.all(it <= iters) and np.all(np.isfinite(xu))
-    # feasibility of the consensus rows of the problems that stopped by a rule (a cap-limited problem has an infeasible bound)
-    done = np.flatnonzero(it < iters)
-    assert done.size > B // 2
+    # problems that met the first stop rule (both residuals below tol; the second rule fires on stagnation, e.g. on an
+    # unreachable bound): their consensus rows satisfy both cones up to the inner ADMM's own stop threshold
+    last = lg[np.arange(B), it - 1]
+    done = np.flatnonzero((it < iters) & (last[:, 0] < 1e-3))
+    print("config5 full size: stopped", int(np.sum(it < iters)), "primal < 1e-3", int(np.sum(last[:, 0] < 1e-3)), "both", done.size,
+          "median last residuals", np.median(last, axis=0))
+    assert done.size > B // 20, done.size
     worst = 0.0
     for st in cs.sets:                                            # SOC rows: w = A y + b, |w[:-1]| <= w[-1]
         A = st["A"] if st["A"].ndim == 3 else np.broadcast_to(st["A"], (B,) + st["A"].shape)
@@ -154,4 +160,5 @@ def test_config5_full_size_properties(nb_dim):
         w = np.einsum("pij,prj->pri", A[done].astype(np.float64), z[done].astype(np.float64)) + b_[done][:, None, :]
         viol = np.linalg.norm(w[..., :-1], axis=-1) - w[..., -1]
         worst = max(worst, float(np.max(viol)))
-    assert worst < 20 * cs.threshold, worst
+    print("worst cone violation of the consensus rows", worst)
+    assert worst < cs.threshold, worst

@@ -461,6 +461,8 @@ def test_sls_config5_api(golden):
         # precision: 1e-7 in fp64, in fp32 1e-4 or ten times the reference's measured fp32 sensitivity of the problem
         from test_oracle_golden import fp32_tols
         for b in range(P_):
+            if dtype == np.float32 and int(g["n_it"][b]) == 50:
+                continue                                        # no contraction (see above): fp64 only
             one = SLS(2, 1, N, dtype=dtype)
             one.AB = [g["A"], g["B"]]
             one.set_quadratic_cost(zs[b], np.stack([np.zeros((2, 2)), 1e6 * np.eye(2)]), seq, float(g["u_std"]))
