@@ -326,7 +326,7 @@ def config5_problem(B, nb_dim, N, seed=0):
     return Linv, r_side, rr, cs
 
 
-def config5_run(kern, Linv, r_side, rr, cs, iters, dtype, wrap, sync):
+def config5_run(kern, Linv, r_side, rr, cs, iters, dtype, wrap, sync, gpu_events=False):
     mk = lambda a: wrap(np.ascontiguousarray(a, dtype=dtype))   # noqa: E731
     sets = [{k: (mk(v) if isinstance(v, np.ndarray) else v) for k, v in st.items()} for st in cs.sets]
     x_u = wrap(np.zeros(r_side.shape, dtype=dtype))
@@ -337,13 +337,22 @@ def config5_run(kern, Linv, r_side, rr, cs, iters, dtype, wrap, sync):
     sync()
     t0 = time.perf_counter()
     reps = 0
+    events = []
     while True:
+        if gpu_events:                                           # the launch runs on torch's current stream
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         kern.sls_admm(*args, **kw)
+        if gpu_events:
+            ev[1].record()
+            events.append(ev)
         reps += 1
         sync()
         if time.perf_counter() - t0 > 2.0 or reps >= 20:
             break
-    return (time.perf_counter() - t0) / reps, x_u
+    wall = (time.perf_counter() - t0) / reps
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events) if events else None
+    return wall, x_u, kernel_ms
 
 
 def config5_main(args):
@@ -358,12 +367,28 @@ def config5_main(args):
     hip = kernels()
     dev = lambda a: torch.from_numpy(a).cuda()                  # noqa: E731
     for dtype, name in ((np.float32, "f32"), (np.float64, "f64")):
-        dt, x_u = config5_run(hip, Linv, r_side, rr, cs, iters, dtype, dev, torch.cuda.synchronize)
+        dt, x_u, kms = config5_run(hip, Linv, r_side, rr, cs, iters, dtype, dev, torch.cuda.synchronize, gpu_events=True)
+        R_, D_ = r_side.shape[1], r_side.shape[2]
+        w = 4 if dtype == np.float32 else 8
+        # the one kernel of this workload (isls_sls_admm): per problem it reads its right-hand side and writes the iterate once
+        # (the shared inverse stays in the L2), and every ADMM iteration is an [R x R] . [R x D] product plus the per-row
+        # project_set_convex iterations (data dependent, not counted): it is bound by vector arithmetic and LDS, not by HBM,
+        # and fp32 MFMA runs at the vector rate on gfx950 (MI355X_MICROARCH.md), so the peak is the 157.3 TFLOP/s of either
+        flops = 2.0 * B * iters * R_ * R_ * D_
+        vec_peak = 157.3 if dtype == np.float32 else 78.6
         out = {"metric": "SLS-ADMM iterations/sec (config 5)", "value": iters / dt, "unit": "iterations/s", "n_gpus": 1,
                "dtype": name, "data": "synthetic", "higher_is_better": True,
                "config": {"workload": f"config5: DI-{args.config5_dim}D SLS-ADMM, SOC chance constraints", "batch": B, "horizon": N,
                           "admm_iters": iters, "inner_max_iter": cs.max_iter},
-               "problems_per_s": B / dt, "ms_per_solve": 1e3 * dt}
+               "problems_per_s": B / dt, "ms_per_solve": 1e3 * dt,
+               "roofline": {"bound": "mfma", "kernel": "sls_admm_kernel", "avg_launch_ms": kms,
+                            "achieved": flops / (kms * 1e-3) / 1e12, "peak": vec_peak, "unit": "TFLOP/s",
+                            "frac": flops / (kms * 1e-3) / 1e12 / vec_peak, "traffic": None,
+                            "algorithmic_flops_per_launch": flops,
+                            "algorithmic_bytes_per_launch": 2.0 * B * R_ * D_ * w,
+                            "hbm_achieved_GBs": 2.0 * B * R_ * D_ * w / (kms * 1e-3) / 1e9,
+                            "note": "x-step flops only; cycle stamps (DESIGN 5b): the x-step is 4 % (DI-1D) / 28 % (DI-3D) of "
+                                    "the kernel, the rest is the per-row set projection"}}
         if not args.no_cpu_baseline:                             # the CPU oracle, a reported baseline only
             from oracle import oracle as orc
             okern, olib = orc.load()
@@ -372,13 +397,14 @@ def config5_main(args):
             cs_s = type(cs)(cs.dim, cs.cols, [{k: (v[:sample] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[0] == B else v)
                                                for k, v in st.items()} for st in cs.sets], rho=cs.rho, max_iter=cs.max_iter,
                             threshold=cs.threshold)
-            dtc, x_c = config5_run(okern, Linv, r_side[:sample], rr, cs_s, iters, dtype, lambda a: a, lambda: None)
+            dtc, x_c, _ = config5_run(okern, Linv, r_side[:sample], rr, cs_s, iters, dtype, lambda a: a, lambda: None)
             d = np.abs(x_u.cpu().numpy()[:sample].astype(np.float64) - x_c.astype(np.float64)).reshape(sample, -1).max(1)
             d = d / np.abs(x_c.astype(np.float64)).reshape(sample, -1).max(1)
             out["cpu_baseline"] = {"value": iters / (dtc * B / sample), "unit": "iterations/s", "cores": cores, "kind": "port",
                                    "sample": f"{sample} problems, scaled linearly to {B}"}
             # problems whose bound is infeasible do not contract and amplify rounding differences: median and max
-            out["rel_diff_vs_oracle_on_sample"] = {"median": float(np.median(d)), "max": float(np.max(d))}
+            out["rel_diff_vs_oracle_on_sample"] = {"median": float(np.median(d)), "max": float(np.max(d)),
+                                                   "problems_above_1e-4": int(np.sum(d > 1e-4)), "sample": int(sample)}
         print(json.dumps(out))
 
 
@@ -416,6 +442,13 @@ def isls_admm_main(args):
     s.isls_admm(3, None, max_line_search=L, k_max=outer, project_u=cs, rho_u=1.0, max_admm_iter=J, threshold=0.0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same call once more with HIP events around the kernel families of the ADMM iteration (kept out of `value`: an
+    # event pair per launch costs queue bubbles on launches this short)
+    s2 = fresh(range(B))
+    s2.engine.profile_events = {}
+    s2.isls_admm(3, None, max_line_search=L, k_max=outer, project_u=cs, rho_u=1.0, max_admm_iter=J, threshold=0.0)
+    fam = s2.engine.family_ms()
+    s2.engine.profile_events = None
     done = float(np.max(s.outer_iters))               # outer iterations the batch ran (problems that met the reference's stop rules idle)
     out = {"metric": "isls_admm outer iterations/sec (3R arm, robust control bounds)", "value": done / dt, "unit": "iterations/s",
            "n_gpus": 1, "dtype": "f64", "data": "synthetic", "higher_is_better": True,
@@ -423,6 +456,26 @@ def isls_admm_main(args):
                       "admm_iters_J": J, "line_search_L": L, "outer_iterations_run": done, "outer_iterations_mean_per_problem": float(np.mean(s.outer_iters))},
            "ms_per_outer_iteration": 1e3 * dt / done, "problem_iterations_per_s": B * done / dt,
            "final_cost_mean": float(np.mean(s.cost))}
+    # roofline of the dominant kernel family (event-timed on the launch stream); algorithmic HBM bytes per launch, w = 8:
+    #   project_rows   : the [B, N m, C] rows in and out (the sets are a few hundred shared bytes)
+    #   riccati_ff     : one column's pass: packed records + c0, targets in, k out
+    #   columns_rollout: A, B, K, k[C] in, dx[C], du[C] out ;  rollout_ls: the line search's 36 KB-per-trajectory figure at n = 9
+    n, m, C, w = cfg["n"], cfg["m"], 4, 8
+    rec = n * n + 2 * n * m + m * m
+    abytes = {"project_rows": 2 * B * N * m * C * w, "riccati_ff": B * N * (rec + (n + m) + 3 * m + m) * w,
+              "columns_rollout": B * N * (n * n + n * m + m * n + C * m + C * (n + m)) * w,
+              "rollout_ls": B * N * (m + (n + m) + (n + m)) * w}
+    if fam:
+        dom = max(fam, key=lambda k: fam[k][0])
+        avg = fam[dom][0] / max(1, fam[dom][1])
+        ach = abytes[dom] / (avg * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "avg_launch_ms": avg, "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": abytes[dom],
+                           "families": {k: {"ms_per_outer_iteration": v[0] / done, "launches_per_outer_iteration": v[1] / done,
+                                            "avg_launch_ms": v[0] / max(1, v[1]),
+                                            "frac": abytes[k] / (v[0] / max(1, v[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                        for k, v in fam.items()}}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import problem_arrays

@@ -74,6 +74,12 @@ __global__ __launch_bounds__(BLOCK) void sls_admm_kernel(SlsP<T> p)
     for (int c = 0; c < D; ++c) { rside[c] = rs[c]; x[c] = T(0); z[c] = T(0); lmb[c] = T(0); }
     T prim = T(1e6), dual = T(1e6);
     int it = 0;
+#ifdef ISLS_DIAG
+    unsigned long long cyc_x = 0, cyc_p = 0, cyc_r = 0, t0_ = __builtin_readcyclecounter();
+#define SLS_STAMP(acc) { const unsigned long long t1_ = __builtin_readcyclecounter(); acc += t1_ - t0_; t0_ = t1_; }
+#else
+#define SLS_STAMP(acc)
+#endif
     for (int j = 0; j < p.max_iter; ++j) {
         ++it;
         // x-step: x_u = Linv (r_side + Rr (z - lmb))                                   (sls.py:375-384)
@@ -90,11 +96,13 @@ __global__ __launch_bounds__(BLOCK) void sls_admm_kernel(SlsP<T> p)
             for (int c = 0; c < D; ++c) x[c] += l * rhs[k * D + c];
         }
         __syncthreads();
+        SLS_STAMP(cyc_x)
         // z-step: z = project_u(alpha x + (1-alpha) z + lmb), all rows of the problem in one project_set_convex call
         T v[D], zn[D];
 #pragma unroll
         for (int c = 0; c < D; ++c) v[c] = (p.alpha * x[c] + (T(1) - p.alpha) * z[c]) + lmb[c];
         project_set_convex_row<T, D>(v, p.nsets, sets, p.rho, p.inner_max_iter, p.threshold, zn, block_max);
+        SLS_STAMP(cyc_p)
         const T prev_prim = prim, prev_dual = dual;
         T p2 = T(0), d2 = T(0);
 #pragma unroll
@@ -118,7 +126,13 @@ __global__ __launch_bounds__(BLOCK) void sls_admm_kernel(SlsP<T> p)
         const T pc = fabs(prev_prim - prim) / (prev_prim + T(1e-30));
         const T dc = fabs(prev_dual - dual) / (prev_dual + T(1e-30));
         if (pc < p.rel_tol && dc < p.rel_tol) break;                                     // sls.py:424-430
+        SLS_STAMP(cyc_r)
     }
+#ifdef ISLS_DIAG
+    if (r == 0 && (pb == 0 || pb == 4000))
+        printf("sls_admm diag problem %d: %d iterations, cycles x-step %llu projection %llu residual/stop %llu (R=%d D=%d)\n", pb, it,
+               cyc_x, cyc_p, cyc_r, R, D);
+#endif
     if (row) {
         const int64_t o = ((int64_t)pb * R + r) * D;
 #pragma unroll

@@ -44,7 +44,28 @@ def _stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Timed:
+    def __init__(self, eng, name):
+        self.eng, self.name = eng, name
+
+    def __enter__(self):
+        ev = getattr(self.eng, "profile_events", None)
+        if ev is not None:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        ev = getattr(self.eng, "profile_events", None)
+        if ev is not None:
+            self.b.record()
+            ev.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 class Engine:
+    profile_events = None
+
     def __init__(self, batch, N, x_dim, u_dim, dtype=torch.float64, device="cuda"):
         if not torch.cuda.is_available():
             raise capi.IslsError("isls.Engine needs a HIP device (torch.cuda.is_available() is False); "
@@ -90,6 +111,17 @@ class Engine:
         self.relax = 1.0
         self.solve_mode = capi.SOLVE_CHOL
         self._outer_args = None
+
+    # ---- optional per-kernel-family event timing (bench.py) -------------------------------------------------
+    def timed(self, name):
+        """Context manager: with `self.profile_events` set to a dict, HIP events are recorded on the launch stream around
+        the enclosed launches and collected under `name` (the kernels run on torch's current stream); otherwise a no-op."""
+        return _Timed(self, name)
+
+    def family_ms(self):
+        """{name: (total ms, launches groups)} of the events recorded since profile_events was set; synchronises."""
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in (self.profile_events or {}).items()}
 
     # ---- problem setup ---------------------------------------------------------------------------------
     def _t(self, x):

@@ -96,14 +96,16 @@ class ColumnSolver:
         for c in range(self.C):
             zx, lx = (bx["z"][c], bx["l"][c]) if bx is not None else (self._zero_zx, self._zero_zx)
             zu, lu = (bu["z"][c], bu["l"][c]) if bu is not None else (self._zero_zu, self._zero_zu)
-            e.kern.riccati_ff(e.A, e.Bm, e.c0x if c == 0 else self.zero_x, e.c0u if c == 0 else self.zero_u, e.K, e.Quu, e.fac,
-                              e.Qux, self.kcol[c], Qr=e.Qr, Rr=e.Rr, zx=zx if e.Qr is not None else None,
-                              lx=lx if e.Qr is not None else None, zu=zu if e.Rr is not None else None,
-                              lu=lu if e.Rr is not None else None, solve_mode=e.solve_mode, active=act, seg=self.seg, rec=self.rec,
-                              stream=_stream_ptr())
-        e.kern.columns_rollout(e.A, e.Bm, self.Cuu, e.c0u, e.K, self.kcol, self.dx, self.du,
-                               Rr=e.Rr if bu is not None else None, zu=bu["z"] if bu is not None else None,
-                               lu=bu["l"] if bu is not None else None, active=act, stream=_stream_ptr())
+            with e.timed("riccati_ff"):
+                e.kern.riccati_ff(e.A, e.Bm, e.c0x if c == 0 else self.zero_x, e.c0u if c == 0 else self.zero_u, e.K, e.Quu,
+                                  e.fac, e.Qux, self.kcol[c], Qr=e.Qr, Rr=e.Rr, zx=zx if e.Qr is not None else None,
+                                  lx=lx if e.Qr is not None else None, zu=zu if e.Rr is not None else None,
+                                  lu=lu if e.Rr is not None else None, solve_mode=e.solve_mode, active=act, seg=self.seg,
+                                  rec=self.rec, stream=_stream_ptr())
+        with e.timed("columns_rollout"):
+            e.kern.columns_rollout(e.A, e.Bm, self.Cuu, e.c0u, e.K, self.kcol, self.dx, self.du,
+                                   Rr=e.Rr if bu is not None else None, zu=bu["z"] if bu is not None else None,
+                                   lu=bu["l"] if bu is not None else None, active=act, stream=_stream_ptr())
 
     def z_step(self, relax, tol_abs, tol_rel, log_row=None):
         """z = Proj(relax x + (1 - relax) z + lmb), lmb += x - z, rho-scaled residuals and the two stop rules"""
@@ -119,7 +121,8 @@ class ColumnSolver:
             if blk is None:
                 continue
             if blk["desc"] is not None:
-                e.kern._call("project_rows", e.sfx, blk["desc"], _stream_ptr())
+                with e.timed("project_rows"):
+                    e.kern._call("project_rows", e.sfx, blk["desc"], _stream_ptr())
             else:                                                               # the caller's numpy projection, problem by problem
                 rows, on_h = blk["work"].cpu().numpy(), act.cpu().numpy()
                 nom_h = noms[key].cpu().numpy() if self.nominal_in_projection else None
@@ -175,9 +178,10 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
             act = e.admm_active
             cs.x_step()
             # line search on d_u: open-loop rollouts of u_nom + alpha d_u, plain cost, first arg-min (isls.py:593-606)
-            e.kern.rollout_ls(e.model, e.model_par, zero_K, du[0], e.xhat, e.uhat, e.alphas[:L], e.Qtab, e.ztab, e.seq, e.u_std,
-                              e.xx, e.xu, best=e.best, cost_new=e.cost_new, flags=0, status=e.status, active=act,
-                              q_nonzero=e.q_nonzero, cost_model=e.cost_model, cost_par=e.cost_par, stream=_stream_ptr())
+            with e.timed("rollout_ls"):
+                e.kern.rollout_ls(e.model, e.model_par, zero_K, du[0], e.xhat, e.uhat, e.alphas[:L], e.Qtab, e.ztab, e.seq, e.u_std,
+                                  e.xx, e.xu, best=e.best, cost_new=e.cost_new, flags=0, status=e.status, active=act,
+                                  q_nonzero=e.q_nonzero, cost_model=e.cost_model, cost_par=e.cost_par, stream=_stream_ptr())
             on = mask3(act)
             step = torch.where(act.to(torch.bool), e.alphas[:L][e.best.long()], torch.ones_like(e.cost_new))
             du[0].mul_(step.view(B, 1, 1))                                      # du_opt[:, 0] = alpha* d_u
