@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi as capi
+from . import hostpath
 from .admm import ADMM
 from .base import ALPHAS, Base
 from .models import Model
@@ -36,6 +37,7 @@ class iSLS(Base):
         self.cost_log = []
         self._K = self._k = None
         self._user_AB = False
+        self._host_model = self._host_cost = False              # plain Python callables: the line search runs on the host
 
     # ---- setters / getters (isls/isls_base.py:74-158) ------------------------------------------------------
     @property
@@ -44,14 +46,18 @@ class iSLS(Base):
 
     @forward_model.setter
     def forward_model(self, model):
-        if not isinstance(model, Model):
-            raise NotImplementedError(
-                "forward_model must be one of isls.models.{LTI, Planar3R, CarSimple}: the rollout runs inside a HIP "
-                "kernel and cannot call back into Python (arbitrary callables are out of scope, SURVEY 7 'hard parts')")
-        if model.x_dim != self.x_dim or model.u_dim != self.u_dim:
-            raise ValueError("model dimensions do not match x_dim/u_dim")
-        self._forward_model = model
-        self.engine.set_model(model.model_id, model.params())
+        """An `isls.models` descriptor selects the device implementation of the rollout.  A plain callable
+        `f(x[R,n], u[R,m]) -> [R,n]` (the reference's convention, isls/isls.py:153,332) is accepted too: the Riccati passes
+        and the ADMM update stay on the GPU, the line-search rollouts go through the callable on the host (hostpath.py)."""
+        if isinstance(model, Model):
+            if model.x_dim != self.x_dim or model.u_dim != self.u_dim:
+                raise ValueError("model dimensions do not match x_dim/u_dim")
+            self._forward_model, self._host_model = model, False
+            self.engine.set_model(model.model_id, model.params())
+            return
+        if not callable(model):
+            raise TypeError("forward_model must be an isls.models descriptor or a callable f(x, u)")
+        self._forward_model, self._host_model = model, True
 
     @property
     def cost_function(self):
@@ -62,13 +68,18 @@ class iSLS(Base):
         """None -> the via-point quadratic cost of set_cost_variables; an `isls.costs` object (PseudoHuber) -> that cost
         on the device, for the line search and for the expansion (the reference's cost_function / get_Cs pair)."""
         if function is None:
-            self._cost_function = None
+            self._cost_function, self._host_cost = None, False
             return
-        if not hasattr(function, "cost_model"):
-            raise NotImplementedError("cost_function must be an isls.costs object (PseudoHuber): the line search evaluates "
-                                      "the cost inside a HIP kernel and cannot call back into Python")
         self._cost_function = function
-        self.engine.set_cost_model(function.cost_model, function.params())
+        if hasattr(function, "cost_model"):
+            self._host_cost = False
+            self.engine.set_cost_model(function.cost_model, function.params())
+        elif callable(function):
+            # the reference's `cost_function(x[L,N,n], u[L,N,m]) -> [L]` (isls.py:360): evaluated on the host for every
+            # candidate of the line search; its expansion comes from the caller's get_Cs
+            self._host_cost = True
+        else:
+            raise TypeError("cost_function must be None, an isls.costs object or a callable cost(x, u)")
 
     @property
     def AB(self):
@@ -90,8 +101,30 @@ class iSLS(Base):
 
     @nominal_values.setter
     def nominal_values(self, value):
-        self.engine.set_nominal(self._batched(value[0], 2), self._batched(value[1], 2))
+        e = self.engine
+        if e.Qtab is None:                                      # no via-point cost (a callable cost only): a zero table
+            e.set_quadratic_cost(np.zeros((1, self.x_dim)), np.zeros((1, self.x_dim, self.x_dim)), np.zeros(self.N, dtype=np.int32), 0.0)
+        e.set_nominal(self._batched(value[0], 2), self._batched(value[1], 2))
+        if self._host_cost:                                     # the nominal's cost through the caller's function
+            self._refresh_host_cost(reset_history=True)
         self.cost_log.append(self.cost)
+
+    def _refresh_host_cost(self, reset_history=False):
+        e = self.engine
+        e.cost.copy_(e._t(hostpath.nominal_cost(self)))
+        if reset_history:
+            e.cost_hist[:, 0] = e.cost
+
+    @property
+    def _host_ls(self):
+        return self._host_model or self._host_cost
+
+    def _line_search(self, L, flags=0, active=None):
+        """Line search over alphas[:L]: the rollout kernel, or the host route when the model / cost is a Python callable."""
+        if self._host_ls:
+            hostpath.line_search(self, L, flags, active)
+        else:
+            self.engine.rollout(L, flags=flags, active=active)
 
     @property
     def x_nom(self):
@@ -143,9 +176,10 @@ class iSLS(Base):
     def _linearize(self, get_AB):
         e = self.engine
         model = self._forward_model
-        if get_AB is None or getattr(get_AB, "__self__", None) is model:
-            if model is None:
-                raise ValueError("set forward_model (isls.models.*) or pass get_AB")
+        if get_AB is None or (getattr(get_AB, "__self__", None) is model and not self._host_model):
+            if model is None or self._host_model:
+                raise ValueError("set forward_model to an isls.models descriptor or pass get_AB (a callable forward model has no "
+                                 "built-in linearisation)")
             if self._user_AB:                                   # restore the engine's own dense buffers
                 z = lambda *s: torch.zeros(*s, dtype=e.dtype, device=e.device)   # noqa: E731
                 e.A, e.Bm = z(e.B, e.N, e.n, e.n), z(e.B, e.N, e.n, e.m)
@@ -183,6 +217,18 @@ class iSLS(Base):
         """Closed-loop rollout of the candidates k[l] (isls/isls.py:310-334): returns (x_log [L,N,n], u_log [L,N,m])."""
         e = self.engine
         k = np.asarray(k, dtype=np.float64)                     # [L,N,m] (batch == 1) or [B,L,N,m]
+        if self._host_model:
+            if self.batch != 1:
+                raise NotImplementedError("rollout_DP through a callable forward model: batch == 1")
+            K = np.asarray(K, dtype=np.float64)
+            xn, un, f = self.x_nom, self.u_nom, self._forward_model
+            x = np.tile(xn[0], (k.shape[0], 1))
+            x_log, u_log = np.zeros((k.shape[0], self.N, self.x_dim)), np.zeros((k.shape[0], self.N, self.u_dim))
+            for i in range(self.N):
+                u = (x - xn[i]) @ K[i].T + k[:, i] + un[i]
+                u_log[:, i], x_log[:, i] = u, x
+                x = np.asarray(f(x, u), dtype=np.float64)
+            return x_log, u_log
         if k.ndim == 3 and self.batch > 1:
             k = np.broadcast_to(k[None], (self.batch,) + k.shape)
         Kt = e._t(self._batched(K, 3))
@@ -206,7 +252,7 @@ class iSLS(Base):
         e.status.zero_()
         e.gain(active=e.outer_active)
         e.feedforward(active=e.outer_active)
-        e.rollout(max_line_search, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST, active=e.outer_active)
+        self._line_search(max_line_search, flags=capi.RO_NAN_TO_1E5 | capi.RO_ACCEPT_TEST, active=e.outer_active)
         st = e.status.cpu().numpy()
         ok = (st & capi.ST_LS_REJECT) == 0
         if (st & capi.ST_NOT_PD).any():
@@ -229,13 +275,13 @@ class iSLS(Base):
         e = self.engine
         e.outer_active.fill_(1)
         prev = np.atleast_1d(np.array(self.cost, dtype=np.float64)).copy()
+        Cts = cts = None
         for i in range(max_iter):
             if verbose:
                 print("Iteration", i)
             if not (is_dynamics_linear and i > 0):
                 self._linearize(get_AB)
-            Cts = cts = None
-            self._check_get_Cs(get_Cs)
+            Cts, cts = self._user_expansion(get_Cs) if not (is_cost_quadratic and i > 0) else (Cts, cts)
             if method == 'dp':
                 ok, _, _ = self.iterate_once_dp(max_line_search=max_line_search_iter, verbose=verbose, Cts=Cts, cts=cts,
                                                 _linearized=True)
@@ -259,15 +305,23 @@ class iSLS(Base):
                 break
         return None
 
+    def _device_expansion(self, get_Cs):
+        """True when the device expands the cost itself: no get_Cs, or the get_Cs of the isls.costs object on the device."""
+        return get_Cs is None or (self._cost_function is not None and not self._host_cost and
+                                  getattr(get_Cs, "__self__", None) is self._cost_function)
+
+    def _user_expansion(self, get_Cs):
+        """(Cts, cts) from the caller's derivative callback `cts, Cts = get_Cs(x_nom, u_nom)` (isls/isls.py:102), evaluated
+        on the host per trajectory -- or (None, None) when the device expands the cost itself."""
+        if self._device_expansion(get_Cs):
+            if self._host_cost and get_Cs is None:
+                raise ValueError("a callable cost_function needs get_Cs (its gradient / Hessian along the nominal)")
+            return None, None
+        return hostpath.expansion(self, get_Cs)
+
     def _check_get_Cs(self, get_Cs):
-        """get_Cs is the derivative callback of the user's cost (isls/isls.py:102).  With a built-in cost model the
-        device expands that same cost itself, so the only get_Cs that keeps the semantics is the cost object's own."""
-        if get_Cs is None:
-            return
-        if self._cost_function is None or getattr(get_Cs, "__self__", None) is not self._cost_function:
-            raise NotImplementedError("get_Cs is accepted only as `cost.get_Cs` of the isls.costs object assigned to "
-                                      "cost_function (the device expands that cost itself); arbitrary derivative "
-                                      "callbacks would need a matching device cost for the line search")
+        if self._host_cost and get_Cs is None:
+            raise ValueError("a callable cost_function needs get_Cs (its gradient / Hessian along the nominal)")
 
     def solve_ilqr(self, get_AB=None, max_ilqr_iter=100, max_line_search_iter=25, dp=True, verbose=False, **kw):
         """Notebook-era name (Car notebooks :254): iLQR with the quadratic cost set by set_cost_variables."""
@@ -282,7 +336,8 @@ class iSLS(Base):
         linearise, expand, then max_admm_iter x [ff pass, line search over alphas[:max_line_search_iter] without
         acceptance test, z/lambda update] with lambda reset and z warm-started, nominal <- last x-step, and the
         stop rules |dcost| < 1e-3 / oscillation < 1e-3.  Returns the residual log of the last outer iteration."""
-        self._check_get_Cs(get_Cs)
+        if self._host_cost and get_Cs is None:
+            raise ValueError("a callable cost_function needs get_Cs (its gradient / Hessian along the nominal)")
         max_iter = k_max if k_max is not None else max_iter
         L = max_line_search if max_line_search is not None else max_line_search_iter
         tol = threshold if threshold is not None else tol
@@ -290,6 +345,7 @@ class iSLS(Base):
         px, pu = self._projection(project_x, self.x_dim), self._projection(project_u, self.u_dim)
         on_device = (Box, ConvexSets)
         host_proj = (px is not None and not isinstance(px, on_device)) or (pu is not None and not isinstance(pu, on_device))
+        host_proj = host_proj or self._host_ls                  # a host line search: the whole ADMM loop is host driven
         xs = px if isinstance(px, ConvexSets) and not host_proj else None
         us = pu if isinstance(pu, ConvexSets) and not host_proj else None
         xb = px.bounds(self.N, self.x_dim) if isinstance(px, Box) else ((-np.inf, np.inf) if px is not None and xs is None else None)
@@ -303,7 +359,7 @@ class iSLS(Base):
         logs = []
         for j in range(max_iter):
             self._linearize(get_AB)
-            e.expand()
+            self._expand_regularised(get_Cs)
             if host_proj:
                 logs = self._admm_host(px, pu, L, J, tol, alpha, verbose)
             else:
@@ -325,6 +381,21 @@ class iSLS(Base):
         # `self.admm_iters` tells how many are real per trajectory
         self.admm_iters = e.admm_iters.cpu().numpy()
         return logs[:int(self.admm_iters[0])] if self.batch == 1 and not host_proj else logs
+
+    def _expand_regularised(self, get_Cs):
+        """Quadratic expansion about the nominal plus the ADMM regulariser's Hessians: on the device for the built-in costs,
+        from the caller's get_Cs otherwise (gradients of the regulariser are added by the feed-forward pass either way)."""
+        e = self.engine
+        if self._device_expansion(get_Cs):
+            e.Cux = None
+            e.expand()
+            return
+        Cts, cts = hostpath.expansion(self, get_Cs)
+        self._expand(Cts, cts)
+        if e.Qr is not None:
+            e.Cxx.add_(2.0 * (e.Qr if e.Qr.ndim == 4 else e.Qr.unsqueeze(0)))
+        if e.Rr is not None:
+            e.Cuu.add_(2.0 * (e.Rr if e.Rr.ndim == 4 else e.Rr.unsqueeze(0)))
 
     def _admm_host(self, px, pu, L, J, tol, alpha, verbose):
         """Generic route for projections without a device kernel: x-step on the GPU, z-step through the caller's
@@ -348,7 +419,7 @@ class iSLS(Base):
                 e.zu.copy_(e._t(z_u.reshape(B, N, m))), e.lu.copy_(e._t(l_u.reshape(B, N, m)))
             act_t = torch.as_tensor(active.astype(np.int32), device=e.device)
             e.feedforward(active=act_t)
-            e.rollout(L, active=act_t)
+            self._line_search(L, active=act_t)
             xx, xu = e.xx.cpu().numpy().reshape(B, -1), e.xu.cpu().numpy().reshape(B, -1)
             cur = np.zeros((B, 2))
             for b in range(B):
@@ -400,9 +471,19 @@ class iSLS(Base):
     def get_trajectory_sls(self, x0, K, k, noise_scale=0, problem=0):
         """Monte-Carlo closed loop of the dense controller about the nominal of problem `problem` through the forward model
         (isls/isls_base.py:28-42): x0 [M, n] -> (x_log [M,N,n], u_log [M,N,m]); one device thread per initial state."""
-        if noise_scale:
-            raise NotImplementedError("process noise is drawn on the host in the reference; not built")
         e = self.engine
+        if noise_scale or self._host_model:
+            # process noise comes from numpy's global generator, one draw per step in the reference's order: host loop
+            # through the (numpy-callable) forward model, isls/isls_base.py:28-42
+            K, k = np.asarray(K, dtype=np.float64), np.asarray(k, dtype=np.float64)
+            xn, un = e.xhat[problem].cpu().numpy().astype(np.float64), e.uhat[problem].cpu().numpy().astype(np.float64)
+            n, m = self.x_dim, self.u_dim
+
+            def control(i, x_log):
+                xv = np.zeros((x_log.shape[0], self.N * n))
+                xv[:, :(i + 1) * n] = (x_log[:, :i + 1] - xn[None, :i + 1]).reshape(x_log.shape[0], -1)
+                return (xv @ K.T + k)[:, i * m:(i + 1) * m] + un[i]
+            return hostpath.noisy_closed_loop(self._forward_model, x0, self.N, m, control, noise_scale)
         x0 = np.asarray(x0, dtype=np.float64)
         single = x0.ndim == 1
         x0 = np.atleast_2d(x0)
@@ -496,9 +577,13 @@ class iSLS(Base):
     def get_trajectory_dp(self, x0, K, k, noise_scale=0):
         """u_t = K_t x_t + k_t, x_{t+1} = f(x_t, u_t) from x0 (absolute form), noise-free only.  x0 [n] (or [B,n]): one
         trajectory per problem of the batch; x0 [M,n] with batch == 1: M initial states against the same controller."""
-        if noise_scale:
-            raise NotImplementedError("process noise is drawn on the host in the reference; not built")
         e = self.engine
+        if noise_scale or self._host_model:                          # isls/isls_base.py:59-71 on the host (see get_trajectory_sls)
+            K, k = np.asarray(K, dtype=np.float64), np.asarray(k, dtype=np.float64)
+            if K.ndim == 4 or k.ndim == 3:
+                raise NotImplementedError("noisy / callable-model closed loops take one controller (K [N,m,n], k [N,m])")
+            return hostpath.noisy_closed_loop(self._forward_model, x0, self.N, self.u_dim,
+                                              lambda i, x_log: x_log[:, i] @ K[i].T + k[i], noise_scale)
         x0 = np.asarray(x0, dtype=np.float64)
         if x0.ndim == 2 and self.batch == 1 and x0.shape[0] != 1:      # Monte Carlo over initial states: a batch of M rollouts
             mc = iSLS(self.x_dim, self.u_dim, self.N, batch=x0.shape[0], dtype=self.np_dtype, device=e.device)

@@ -152,7 +152,7 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     notebook cell 25 is applied on the device), or a callable `(rows [N d, 1 + dim], nominal [N, d]) -> rows` in the
     reference's convention (host round trip per ADMM iteration).  `self.admm_iters` holds the executed ADMM iterations of
     the last outer iteration per problem, `self.admm_logs` their (prim, dual) residuals [J, B, 2]."""
-    self._check_get_Cs(get_Cs)
+    self._check_get_Cs(get_Cs)                                                  # a callable cost needs its get_Cs
     e = self.engine
     B, N, n, m, C = self.batch, self.N, self.x_dim, self.u_dim, int(dim) + 1
     if not 1 <= dim <= n or C > capi.MAX_ROW_DIM:
@@ -171,17 +171,21 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     mask3 = lambda a: a.to(torch.bool).view(B, 1, 1)                          # noqa: E731
     for k in range(k_max):
         self._linearize(get_AB)
-        e.expand()
+        self._expand_regularised(get_Cs)                                        # built-in cost on the device, else the caller's get_Cs (isls.py:548-560)
         cs.prepare(e.outer_active)
         cs.restart(e.outer_active)                                              # lmb restarts, z is warm-started (isls.py:613-616)
         for j in range(J):
             act = e.admm_active
             cs.x_step()
             # line search on d_u: open-loop rollouts of u_nom + alpha d_u, plain cost, first arg-min (isls.py:593-606)
-            with e.timed("rollout_ls"):
-                e.kern.rollout_ls(e.model, e.model_par, zero_K, du[0], e.xhat, e.uhat, e.alphas[:L], e.Qtab, e.ztab, e.seq, e.u_std,
-                                  e.xx, e.xu, best=e.best, cost_new=e.cost_new, flags=0, status=e.status, active=act,
-                                  q_nonzero=e.q_nonzero, cost_model=e.cost_model, cost_par=e.cost_par, stream=_stream_ptr())
+            if self._host_ls:                                                   # callable model / cost: the open-loop search on the host
+                from . import hostpath
+                hostpath.line_search(self, L, 0, act, K=np.zeros((B, N, m, n)), k=du[0].cpu().numpy().astype(np.float64), plain_only=True)
+            else:
+                with e.timed("rollout_ls"):
+                    e.kern.rollout_ls(e.model, e.model_par, zero_K, du[0], e.xhat, e.uhat, e.alphas[:L], e.Qtab, e.ztab, e.seq, e.u_std,
+                                      e.xx, e.xu, best=e.best, cost_new=e.cost_new, flags=0, status=e.status, active=act,
+                                      q_nonzero=e.q_nonzero, cost_model=e.cost_model, cost_par=e.cost_par, stream=_stream_ptr())
             on = mask3(act)
             step = torch.where(act.to(torch.bool), e.alphas[:L][e.best.long()], torch.ones_like(e.cost_new))
             du[0].mul_(step.view(B, 1, 1))                                      # du_opt[:, 0] = alpha* d_u
@@ -197,6 +201,8 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
         e.xhat.copy_(torch.where(oa, e.xhat + dx[0], e.xhat))
         e.uhat.copy_(torch.where(oa, e.uhat + du[0], e.uhat))
         e.evaluate_cost()
+        if self._host_cost:
+            self._refresh_host_cost()
         st = e.status.cpu().numpy()
         if (st & capi.ST_NOT_PD).any():
             raise np.linalg.LinAlgError("Quu not positive definite")

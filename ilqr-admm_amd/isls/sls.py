@@ -142,7 +142,13 @@ class SLS(Base):
         """u_t = K_t x_t + k_t, x_{t+1} = A x_t + B u_t  (isls/sls_base.py:76-89).  x0 [n] -> one trajectory per problem
         of the batch; x0 [M,n] with batch == 1 evaluates M initial states against the same controller (Monte Carlo)."""
         if noise_scale:
-            raise NotImplementedError("process noise is drawn on the host in the reference; not built")
+            # process noise comes from numpy's global generator, one draw per step in the reference's order
+            # (isls/sls_base.py:76-89): a host loop, so that a seeded run reproduces the reference's trajectories
+            from . import hostpath
+            K, k = np.asarray(K, dtype=np.float64), np.asarray(k, dtype=np.float64)
+            A, Bm = np.asarray(self.A, dtype=np.float64), np.asarray(self.B, dtype=np.float64)
+            return hostpath.noisy_closed_loop(lambda x, u: x @ A.T + u @ Bm.T, x0, self.N, self.u_dim,
+                                              lambda i, x_log: x_log[:, i] @ K[i].T + k[i], noise_scale)
         x0 = np.asarray(x0, dtype=np.float64)
         e = self.engine
         if x0.ndim == 2 and self.batch == 1 and x0.shape[0] != 1:
@@ -381,8 +387,18 @@ class SLS(Base):
         """Closed loop with the dense causal SLS controller: u_i = (K x_{0..i} + k)_i, x_{i+1} = A x_i + B u_i for a set
         of initial states x0 [M, n] (isls/sls_base.py:91-105) -- the Monte-Carlo evaluation of the notebooks, one device
         thread per initial state."""
-        if noise_scale:
-            raise NotImplementedError("process noise is drawn on the host in the reference; not built")
+        if noise_scale:                                            # isls/sls_base.py:91-105 on the host (see get_trajectory_dp)
+            from . import hostpath
+            K, k = np.asarray(K, dtype=np.float64), np.asarray(k, dtype=np.float64)
+            A, Bm = np.asarray(self.A, dtype=np.float64), np.asarray(self.B, dtype=np.float64)
+            n_, m_ = self.x_dim, self.u_dim
+
+            def control(i, x_log):
+                xv = np.zeros((x_log.shape[0], self.N * n_))
+                xv[:, :(i + 1) * n_] = x_log[:, :i + 1].reshape(x_log.shape[0], -1)
+                return (xv @ K.T + k)[:, i * m_:(i + 1) * m_]
+            return hostpath.noisy_closed_loop(lambda x, u: x @ A.T + u @ Bm.T, np.atleast_2d(np.asarray(x0, dtype=np.float64)),
+                                              self.N, m_, control, noise_scale)
         e = self.engine
         x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
         M, N, n, m = x0.shape[0], self.N, self.x_dim, self.u_dim

@@ -1025,8 +1025,41 @@ def gen_obstacles():
          dp_logs=np.stack(logd), centres=np.stack(centres), radii=np.array(radii))
 
 
+# ---------------------------------------------------------------------------------------------
+# G13: closed loops with process noise (np.random.normal per step) from the unmodified SLS / iSLS, seeded
+# ---------------------------------------------------------------------------------------------
+def gen_noise():
+    c = P.config1(50)
+    sls = ref.SLS(2, 1, 50)
+    sls.AB = [c["A"], c["B"]]
+    sls.set_quadratic_cost(c["zs"], c["Qs"], c["seq"], c["u_std"])
+    K, k = sls.solve_dp()
+    x0s = np.random.default_rng(5).normal(scale=0.1, size=(7, 2))
+    out = dict(K=K, k=k, x0s=x0s)
+    np.random.seed(123)
+    out["dp_x"], out["dp_u"] = sls.get_trajectory_dp(x0s, K, k, noise_scale=0.05)
+    us = np.random.default_rng(6).normal(size=(50, 1))
+    np.random.seed(124)
+    out["batch_us"] = us
+    out["batch_x"], out["batch_u"] = sls.get_trajectory_batch(x0s, us, noise_scale=0.02)
+    # iSLS: the arm through its own numpy forward model, open loop with noise and DP closed loop about zero gains
+    cfg = P.config3(batch=1, N=100, seed=0)
+    f, _ = P.model_callbacks(cfg)
+    isl = RefISLS(9, 3, 100)
+    isl.forward_model = f
+    x0 = cfg["x0"][0]
+    np.random.seed(125)
+    out["arm_x0"], out["arm_us"] = x0, cfg["u0"][0]
+    out["arm_batch_x"], out["arm_batch_u"] = isl.get_trajectory_batch(x0, cfg["u0"][0], noise_scale=0.01)
+    Kz, kz = 0.1 * np.random.default_rng(7).normal(size=(100, 3, 9)), cfg["u0"][0]
+    np.random.seed(126)
+    out["arm_K"] = Kz
+    out["arm_dp_x"], out["arm_dp_u"] = isl.get_trajectory_dp(x0, Kz, kz, noise_scale=0.01)
+    save("g13_noise.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm", "batch_ilqr", "sls_state", "obstacles"]
+    which = sys.argv[1:] or ["di1d", "di3d", "arm", "car", "proj", "sls", "tassa", "isls_admm", "batch_ilqr", "sls_state", "obstacles", "noise"]
     for w in which:
         {"di1d": gen_di1d, "di3d": gen_di3d, "arm": gen_arm, "car": gen_car, "proj": gen_projections, "sls": gen_sls,
-         "tassa": gen_tassa, "isls_admm": gen_isls_admm, "batch_ilqr": gen_batch_ilqr, "sls_state": gen_sls_state, "obstacles": gen_obstacles}[w]()
+         "tassa": gen_tassa, "isls_admm": gen_isls_admm, "batch_ilqr": gen_batch_ilqr, "sls_state": gen_sls_state, "obstacles": gen_obstacles, "noise": gen_noise}[w]()

@@ -422,13 +422,18 @@ def test_ilqr_admm_host_projection_path(golden):
 def test_unbuilt_paths_fail_loudly():
     import isls
     s = isls.iSLS(6, 3, 20)
-    with pytest.raises(NotImplementedError):
-        s.forward_model = lambda x, u: x
+    with pytest.raises(TypeError):
+        s.forward_model = 3.0                                   # neither a model descriptor nor a callable
     with pytest.raises(NotImplementedError):
         s.solve(method='sls')
-    sl = isls.SLS(2, 1, 20)
-    with pytest.raises(NotImplementedError):
-        sl.get_trajectory_dp(np.zeros(2), np.zeros((20, 1, 2)), np.zeros((20, 1)), noise_scale=0.1)
+    s.forward_model = lambda x, u: x                            # a callable model has no built-in linearisation
+    s.set_cost_variables(np.zeros((1, 6)), np.zeros((1, 6, 6)), np.zeros(20, dtype=np.int32), 1e-3)
+    s.nominal_values = np.zeros((20, 6)), np.zeros((20, 3))
+    with pytest.raises(ValueError):
+        s.solve(None, max_iter=1)
+    s.cost_function = lambda x, u: np.zeros(x.shape[0])         # a callable cost needs its get_Cs
+    with pytest.raises(ValueError):
+        s.ilqr_admm(lambda x, u: (np.zeros((20, 6, 6)), np.zeros((20, 6, 3))), max_iter=1)
 
 
 def test_sls_config5_api(golden):
@@ -507,8 +512,6 @@ def test_tassa_car_parking_api(golden):
     s.ilqr_admm(get_Cs=cost.get_Cs, project_u=Box(np.array([-0.5, -2.0]), np.array([0.5, 2.0])), max_iter=3,
                 max_line_search_iter=40, max_admm_iter=5, rho_u=np.diag([1e-1, 1e-2]), tol=0.0)
     _check_final(s, g, "o2", [0, 1], 3, 5, {k: 1e-7 for k in ("xx", "xu", "K", "cost")})
-    with pytest.raises(NotImplementedError):
-        s.solve(get_Cs=lambda x, u: None)
 
 
 def test_admm_lqt_dp_with_convex_sets(golden):
