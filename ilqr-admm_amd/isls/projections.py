@@ -20,8 +20,19 @@ class Box:
         self.lo, self.hi = lo, hi
 
     def __call__(self, x):
-        return np.clip(x, np.broadcast_to(np.asarray(self.lo).reshape(-1), np.shape(x)) if np.ndim(self.lo) > 1 else self.lo,
-                       np.broadcast_to(np.asarray(self.hi).reshape(-1), np.shape(x)) if np.ndim(self.hi) > 1 else self.hi)
+        """x: anything whose last axis is d (or a flat [N*d] vector of N rows, as the ADMM callbacks receive it)."""
+        x = np.asarray(x)
+
+        def fit(v):
+            v = np.asarray(v, dtype=np.float64)
+            if v.ndim == 0 or v.shape == x.shape:
+                return v
+            if v.size == x.size:
+                return v.reshape(x.shape)
+            if x.ndim == 1 and v.ndim == 1 and x.size % v.size == 0:      # per-dimension bounds on a flat [N*d] vector
+                return np.tile(v, x.size // v.size)
+            return v
+        return np.clip(x, fit(self.lo), fit(self.hi))
 
     def bounds(self, N, d):
         """(lo, hi) as float64 arrays broadcastable to [N, d]."""
