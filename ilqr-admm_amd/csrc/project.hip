@@ -7,7 +7,7 @@ namespace isls {
 
 template <typename T>
 struct ProjP {
-    int P, R, nsets, max_iter;
+    int P, R, nsets, max_iter, algorithm;
     T rho, threshold;
     int kind[kMaxSets], dim[kMaxSets];
     const T *A[kMaxSets], *b[kMaxSets], *par[kMaxSets];
@@ -17,6 +17,7 @@ struct ProjP {
     int64_t in_sp, in_sr, out_sp, out_sr;
     int32_t *iters;
     const int32_t *active;
+    const int32_t *row_mask;
 };
 
 // BLOCK = largest workgroup the instance is launched with: up to 256 threads (R <= 256, the usual case: rows = time
@@ -27,9 +28,10 @@ __global__ __launch_bounds__(BLOCK) void project_rows_kernel(ProjP<T> p)
     __shared__ T red[2][16];
     const int pb = blockIdx.x, r = threadIdx.x;
     if (p.active != nullptr && p.active[pb] == 0) return;      // uniform per workgroup
-    const bool row = r < p.R;
+    const bool inr = r < p.R;
+    const bool row = inr && (p.row_mask == nullptr || p.row_mask[inr ? r : 0] != 0);   // rows outside the mask pass through
     T x0[D], x[D];
-    const T *src = p.y_in + (int64_t)pb * p.in_sp + (int64_t)(row ? r : 0) * p.in_sr;
+    const T *src = p.y_in + (int64_t)pb * p.in_sp + (int64_t)(inr ? r : 0) * p.in_sr;
 #pragma unroll
     for (int j = 0; j < D; ++j) x0[j] = src[j];
     CSet<T> sets[kMaxSets];
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(BLOCK) void project_rows_kernel(ProjP<T> p)
         sets[s].par = p.par[s] ? p.par[s] + (int64_t)pb * p.par_sp[s] : nullptr;
     }
     int it = 0;
-    if (p.nsets == 1 && sets[0].A == nullptr) {                // direct primitive
+    if (p.algorithm == ISLS_PROJ_ALG_ADMM && p.nsets == 1 && sets[0].A == nullptr) {   // direct primitive
         T v[kMaxSetDim];
 #pragma unroll
         for (int i = 0; i < kMaxSetDim; ++i) v[i] = i < D ? x0[i < D ? i : 0] : T(0);
@@ -63,12 +65,17 @@ __global__ __launch_bounds__(BLOCK) void project_rows_kernel(ProjP<T> p)
             a = ma;
             b = mb;
         };
-        it = project_set_convex_row<T, D>(x0, p.nsets, sets, p.rho, p.max_iter, p.threshold, x, block_max);
+        if (p.algorithm == ISLS_PROJ_ALG_DYKSTRA)
+            it = dykstra_row<T, D>(x0, p.nsets, sets, p.max_iter, p.threshold, x, block_max);
+        else if (p.algorithm == ISLS_PROJ_ALG_SOC)
+            it = project_soc_row<T, D>(x0, sets[0], p.rho, p.max_iter, p.threshold, x, block_max);
+        else
+            it = project_set_convex_row<T, D>(x0, p.nsets, sets, p.rho, p.max_iter, p.threshold, x, block_max);
     }
-    if (row) {
+    if (inr) {
         T *dst = p.y_out + (int64_t)pb * p.out_sp + (int64_t)r * p.out_sr;
 #pragma unroll
-        for (int j = 0; j < D; ++j) dst[j] = x[j];
+        for (int j = 0; j < D; ++j) dst[j] = row ? x[j] : x0[j];
     }
     if (r == 0 && p.iters) p.iters[pb] = it;
 }
@@ -78,19 +85,23 @@ int launch_project(const isls_project_args &a, hipStream_t s)
 {
     if (a.P < 0 || a.R < 1 || a.R > 1024 || a.d < 1 || a.d > kMaxRowDim || a.nsets < 1 || a.nsets > kMaxSets) return ISLS_ERR_ARG;
     if (!a.y_in || !a.y_out) return ISLS_ERR_ARG;
-    const bool direct = a.nsets == 1 && a.sets[0].A == nullptr;
+    if (a.algorithm < ISLS_PROJ_ALG_ADMM || a.algorithm > ISLS_PROJ_ALG_SOC) return ISLS_ERR_UNSUPPORTED;
+    const bool dyk = a.algorithm == ISLS_PROJ_ALG_DYKSTRA;
+    const bool direct = a.algorithm == ISLS_PROJ_ALG_ADMM && a.nsets == 1 && a.sets[0].A == nullptr;
     for (int i = 0; i < a.nsets; ++i) {
         const isls_cset &c = a.sets[i];
-        if (c.kind < ISLS_SET_BOX || c.kind > ISLS_SET_QUADRATIC) return ISLS_ERR_UNSUPPORTED;
+        if (c.kind < ISLS_SET_BOX || c.kind > ISLS_SET_MULTILINEAR) return ISLS_ERR_UNSUPPORTED;
         if (c.dim < 1 || c.dim > kMaxSetDim) return ISLS_ERR_ARG;
-        if (!direct && (!c.A || !c.b)) return ISLS_ERR_ARG;
+        if (!direct && !dyk && (!c.A || !c.b)) return ISLS_ERR_ARG;
         if (c.kind != ISLS_SET_SOC_UNIT && !c.par) return ISLS_ERR_ARG;
+        if ((direct || dyk) && c.dim != a.d) return ISLS_ERR_ARG;      // the set acts on the row itself
     }
-    if (direct && a.sets[0].dim != a.d) return ISLS_ERR_ARG;
-    if (!direct && (a.max_iter < 1 || !(a.rho > 0))) return ISLS_ERR_ARG;
+    if (a.algorithm == ISLS_PROJ_ALG_SOC && (a.nsets != 1 || a.sets[0].kind != ISLS_SET_SOC_UNIT)) return ISLS_ERR_ARG;
+    if (!direct && a.max_iter < 1) return ISLS_ERR_ARG;
+    if (!direct && !dyk && !(a.rho > 0)) return ISLS_ERR_ARG;
     if (a.P == 0) return ISLS_OK;
     ProjP<T> p = {};
-    p.P = a.P; p.R = a.R; p.nsets = a.nsets; p.max_iter = a.max_iter;
+    p.P = a.P; p.R = a.R; p.nsets = a.nsets; p.max_iter = a.max_iter; p.algorithm = a.algorithm;
     p.rho = (T)a.rho; p.threshold = (T)a.threshold;
     for (int i = 0; i < kMaxSets; ++i) {
         const bool on = i < a.nsets;
@@ -103,7 +114,7 @@ int launch_project(const isls_project_args &a, hipStream_t s)
     }
     p.y_in = (const T *)a.y_in; p.y_out = (T *)a.y_out;
     p.in_sp = a.in_sp; p.in_sr = a.in_sr; p.out_sp = a.out_sp; p.out_sr = a.out_sr;
-    p.iters = a.iters; p.active = a.active;
+    p.iters = a.iters; p.active = a.active; p.row_mask = a.row_mask;
     const int threads = ((a.R + 63) / 64) * 64;
 #define CALL(D_)                                                                                              \
     if (threads <= 256) hipLaunchKernelGGL((project_rows_kernel<T, D_, 256>), dim3(a.P), dim3(threads), 0, s, p); \
@@ -115,7 +126,16 @@ int launch_project(const isls_project_args &a, hipStream_t s)
         default: CALL(4); break;
     }
 #undef CALL
-    return check_launch();
+    int rc = check_launch();
+    if (rc == ISLS_OK && a.next) {                             // next stage, in place on this stage's output
+        isls_project_args nx = *a.next;
+        nx.P = a.P; nx.R = a.R; nx.d = a.d;
+        nx.y_in = a.y_out; nx.y_out = a.y_out;
+        nx.in_sp = nx.out_sp = a.out_sp; nx.in_sr = nx.out_sr = a.out_sr;
+        nx.iters = nullptr; nx.active = a.active;
+        rc = launch_project<T>(nx, s);
+    }
+    return rc;
 }
 template int launch_project<double>(const isls_project_args &, hipStream_t);
 template int launch_project<float>(const isls_project_args &, hipStream_t);

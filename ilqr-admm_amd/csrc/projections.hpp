@@ -28,6 +28,29 @@ struct CSet {
 // numpy sign(): 0 for 0 (project_square_batch puts 0 on the arg-max entry of an all-zero row)
 template <typename T> __device__ __forceinline__ T np_sign(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0)); }
 
+// inverse of the d x d matrix M (SPD: I + rho sum A'A) by Gauss-Jordan without pivoting, in registers
+template <typename T, int D>
+__device__ __forceinline__ void invert_spd(T (&M)[D][D], T (&Inv)[D][D])
+{
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Inv[i][j] = i == j ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const T piv = T(1) / M[k][k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) { M[k][j] *= piv; Inv[k][j] *= piv; }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i != k) {
+                const T f = M[i][k];
+#pragma unroll
+                for (int j = 0; j < D; ++j) { M[i][j] -= f * M[k][j]; Inv[i][j] -= f * Inv[k][j]; }
+            }
+    }
+}
+
 // v[0..dim) <- primitive projection of v (in place)
 template <typename T>
 __device__ __forceinline__ void project_primitive(int kind, int dim, const T *par, T (&v)[kMaxSetDim])
@@ -98,6 +121,72 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
                 if (lo) o = v[i] * sl / nrm;
                 v[i] = o;
             }
+    } else if (kind == ISLS_SET_SHELL) {                       // par = l, u, c[dim]: project_quadratic_batch(y - c, l, u) + c
+        const T l = par[0], u = par[1];
+        const T *c = par + 2;
+        T w[kMaxSetDim], ss = T(0);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) {
+            w[i] = i < dim ? v[i] - c[i] : T(0);
+            ss += w[i] * w[i];
+        }
+        const T val = T(0.5) * ss, nrm = sqrt(ss);
+        const bool hi = val > u, lo = l > val;
+        const T su = sqrt(T(2) * u), sl = sqrt(T(2) * l);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < dim) {
+                T o = w[i];
+                if (hi) o = w[i] * su / nrm;
+                if (lo) o = w[i] * sl / nrm;
+                v[i] = o + c[i];
+            }
+    } else if (kind == ISLS_SET_MULTILINEAR) {                 // par = q, l[q], u[q], M[q*dim]   (project_multilinear)
+        const int q = (int)par[0];
+        const T *l = par + 1, *u = l + q, *Mm = u + q;
+        T Ax[kMaxSetDim], G[kMaxSetDim][kMaxSetDim], Gi[kMaxSetDim][kMaxSetDim], mu[kMaxSetDim];
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < kMaxSetDim; ++j)
+                if (i < q && j < dim) acc += Mm[i * dim + j] * v[j];
+            Ax[i] = acc;
+#pragma unroll
+            for (int k = 0; k < kMaxSetDim; ++k) {             // M M' padded with the identity beyond q
+                T g = (i == k && i >= q) ? T(1) : T(0);
+#pragma unroll
+                for (int j = 0; j < kMaxSetDim; ++j)
+                    if (i < q && k < q && j < dim) g += Mm[i * dim + j] * Mm[k * dim + j];
+                G[i][k] = g;
+            }
+        }
+        invert_spd<T, kMaxSetDim>(G, Gi);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) {
+            T t = Ax[i];
+            if (i < q) {
+                if (Ax[i] > u[i]) t = u[i];
+                if (Ax[i] < l[i]) t = l[i];
+            }
+            Ax[i] = Ax[i] - t;
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < kMaxSetDim; ++k) acc += Gi[i][k] * Ax[k];
+            mu[i] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxSetDim; ++j)
+            if (j < dim) {
+                T acc = T(0);
+#pragma unroll
+                for (int i = 0; i < kMaxSetDim; ++i)
+                    if (i < q) acc += Mm[i * dim + j] * mu[i];
+                v[j] = v[j] - acc;
+            }
     } else if (kind == ISLS_SET_SQUARE) {                      // par = q, l, u, c[q], W[q*q], Winv[q*q]
         const int q = (int)par[0];
         const T l = par[1], u = par[2];
@@ -138,29 +227,6 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
                 for (int j = 0; j < kMaxSetDim; ++j)
                     if (j < q) acc += w[j] * Wi[i * q + j];
                 v[i] = acc + c[i];
-            }
-    }
-}
-
-// inverse of the d x d matrix M (SPD: I + rho sum A'A) by Gauss-Jordan without pivoting, in registers
-template <typename T, int D>
-__device__ __forceinline__ void invert_spd(T (&M)[D][D], T (&Inv)[D][D])
-{
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j < D; ++j) Inv[i][j] = i == j ? T(1) : T(0);
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const T piv = T(1) / M[k][k];
-#pragma unroll
-        for (int j = 0; j < D; ++j) { M[k][j] *= piv; Inv[k][j] *= piv; }
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-            if (i != k) {
-                const T f = M[i][k];
-#pragma unroll
-                for (int j = 0; j < D; ++j) { M[i][j] -= f * M[k][j]; Inv[i][j] -= f * Inv[k][j]; }
             }
     }
 }
@@ -286,6 +352,138 @@ __device__ __forceinline__ int project_set_convex_row(const T (&x0)[D], int nset
             if (pc < T(1e-5) && dc < T(1e-5)) break;
         }
     }
+    return it;
+}
+
+// project_set_convex_dykstra for ONE row (isls/projections.py:465-504): every set acts on the row itself.  block_max as
+// above (one value is enough: the summed squared change of the corrections of a pass).  Returns the passes run.
+template <typename T, int D, typename BlockMax>
+__device__ __forceinline__ int dykstra_row(const T (&x0)[D], int nsets, const CSet<T> (&sets)[kMaxSets], int max_iter, T tol,
+                                           T (&x)[D], BlockMax &&block_max)
+{
+    T u[D], z[kMaxSets][D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) u[j] = x0[j];
+#pragma unroll
+    for (int s = 0; s < kMaxSets; ++s)
+#pragma unroll
+        for (int j = 0; j < D; ++j) z[s][j] = T(0);
+    int k = 0;
+    T cmax = T(10);
+    while (k <= max_iter && cmax >= tol) {                     // np.any(cI >= tol)
+        T cI = T(0);
+#pragma unroll
+        for (int s = 0; s < kMaxSets; ++s)
+            if (s < nsets) {
+                T v[kMaxSetDim], prev_u[D], nn = T(0);
+#pragma unroll
+                for (int j = 0; j < kMaxSetDim; ++j) v[j] = T(0);
+#pragma unroll
+                for (int j = 0; j < D; ++j) { prev_u[j] = u[j]; v[j] = prev_u[j] - z[s][j]; }
+                project_primitive<T>(sets[s].kind, D, sets[s].par, v);
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const T prev_z = z[s][j];
+                    const T zn = v[j] - (prev_u[j] - prev_z);
+                    u[j] = v[j];
+                    z[s][j] = zn;
+                    nn += (prev_z - zn) * (prev_z - zn);
+                }
+                const T nr = sqrt(nn);
+                cI += nr * nr;                                 // np.linalg.norm(...)**2
+            }
+        T dummy = T(0);
+        block_max(cI, dummy);
+        cmax = cI;
+        ++k;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] = u[j];
+    return k;
+}
+
+// project_soc for ONE row (isls/projections.py:163-234): A y + b in the second-order cone by ADMM.
+template <typename T, int D, typename BlockMax>
+__device__ __forceinline__ int project_soc_row(const T (&z0)[D], const CSet<T> &st, T rho, int max_iter, T tol, T (&zo)[D],
+                                               BlockMax &&block_max)
+{
+    const T *A = st.A, *b = st.b;
+    const int dim = st.dim;
+    T M[D][D], Linv[D][D], z[D], lmb[kMaxSetDim];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            T acc = T(0);
+#pragma unroll
+            for (int i = 0; i < kMaxSetDim; ++i)
+                if (i < dim) acc += A[i * D + j] * A[i * D + k];
+            M[j][k] = (j == k ? T(1) : T(0)) + rho * acc;
+        }
+    invert_spd<T, D>(M, Linv);
+#pragma unroll
+    for (int j = 0; j < D; ++j) z[j] = z0[j];
+#pragma unroll
+    for (int i = 0; i < kMaxSetDim; ++i) lmb[i] = T(0);
+    T prim_g = T(1e5), dual_g = T(1e5);
+    int it = 0;
+    for (int j = 0; j < max_iter; ++j) {
+        ++it;
+        T x[kMaxSetDim], zp[D], rs[D];
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i) {
+            T acc = T(0);
+            if (i < dim) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += A[i * D + k] * z[k];
+                acc = (acc + b[i]) + lmb[i];
+            }
+            x[i] = acc;
+        }
+        project_primitive<T>(ISLS_SET_SOC_UNIT, dim, (const T *)nullptr, x);
+#pragma unroll
+        for (int k = 0; k < D; ++k) { zp[k] = z[k]; rs[k] = T(0); }
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < dim) {
+                const T w = (-b[i] + x[i]) - lmb[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) rs[k] += A[i * D + k] * w;
+            }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += Linv[i][k] * (z0[k] + rho * rs[k]);
+            z[i] = acc;
+        }
+        T pn = T(0), dn = T(0);
+#pragma unroll
+        for (int i = 0; i < kMaxSetDim; ++i)
+            if (i < dim) {
+                T acc = T(0);
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += A[i * D + k] * z[k];
+                const T pr = (acc + b[i]) - x[i];
+                lmb[i] += pr;
+                pn += pr * pr;
+            }
+#pragma unroll
+        for (int k = 0; k < D; ++k) dn += (rho * (z[k] - zp[k])) * (rho * (z[k] - zp[k]));
+        pn = sqrt(pn);
+        dn = sqrt(dn);
+        const T prev_p = prim_g, prev_d = dual_g;
+        block_max(pn, dn);
+        prim_g = pn;
+        dual_g = dn;
+        if (prim_g < tol && dual_g < tol) break;
+        if (j != max_iter - 1) {
+            const T pc = fabs(prev_p - prim_g) / (prev_p + T(1e-30)), dc = fabs(prev_d - dual_g) / (prev_d + T(1e-30));
+            if (pc < T(1e-5) && dc < T(1e-5)) break;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) zo[j] = z[j];
     return it;
 }
 

@@ -198,7 +198,7 @@ int launch_sls_admm(const isls_sls_admm_args &a, hipStream_t s)
     if (pj.nsets < 1 || pj.nsets > kMaxSets || pj.max_iter < 1 || !(pj.rho > 0)) return ISLS_ERR_ARG;
     for (int i = 0; i < pj.nsets; ++i) {
         const isls_cset &c = pj.sets[i];
-        if (c.kind < ISLS_SET_BOX || c.kind > ISLS_SET_QUADRATIC) return ISLS_ERR_UNSUPPORTED;
+        if (c.kind < ISLS_SET_BOX || c.kind > ISLS_SET_MULTILINEAR) return ISLS_ERR_UNSUPPORTED;
         if (c.dim < 1 || c.dim > kMaxSetDim || !c.A || !c.b) return ISLS_ERR_ARG;
         if (c.kind != ISLS_SET_SOC_UNIT && !c.par) return ISLS_ERR_ARG;
     }

@@ -17,7 +17,7 @@ try:  # torch is plumbing (device memory, streams); the binding itself works on 
 except Exception:  # pragma: no cover
     torch = None
 
-ABI_VERSION = 102            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
+ABI_VERSION = 103            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
@@ -128,11 +128,11 @@ class CSet(C.Structure):
 
 class ProjectArgs(C.Structure):
     _fields_ = [("P", C.c_int32), ("R", C.c_int32), ("d", C.c_int32), ("nsets", C.c_int32),
-                ("max_iter", C.c_int32), ("_pad", C.c_int32), ("rho", C.c_double), ("threshold", C.c_double),
+                ("max_iter", C.c_int32), ("algorithm", C.c_int32), ("rho", C.c_double), ("threshold", C.c_double),
                 ("sets", CSet * 4),
                 ("y_in", C.c_void_p), ("in_sp", C.c_int64), ("in_sr", C.c_int64),
                 ("y_out", C.c_void_p), ("out_sp", C.c_int64), ("out_sr", C.c_int64),
-                ("iters", C.c_void_p), ("active", C.c_void_p)]
+                ("iters", C.c_void_p), ("active", C.c_void_p), ("row_mask", C.c_void_p), ("next", C.c_void_p)]
 
 
 class SlsAdmmArgs(C.Structure):
@@ -180,7 +180,8 @@ EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             "isls_timing_destroy", "isls_timing_reset", "isls_timing_pause", "isls_timing_read_ms"]
 
 
-SET_BOX, SET_SOC_UNIT, SET_SQUARE, SET_LINEAR, SET_QUADRATIC = 1, 2, 3, 4, 5
+SET_BOX, SET_SOC_UNIT, SET_SQUARE, SET_LINEAR, SET_QUADRATIC, SET_SHELL, SET_MULTILINEAR = 1, 2, 3, 4, 5, 6, 7
+ALG_ADMM, ALG_DYKSTRA, ALG_SOC = 0, 1, 2
 MAX_ROW_DIM, MAX_SET_DIM, MAX_SETS = 4, 5, 4
 
 
@@ -464,7 +465,8 @@ class Kernels:
         return self._call("riccati_ff", _sfx(args[4]), a, stream)
 
     @staticmethod
-    def project_args(y_in, y_out, sets, rho=1.0, max_iter=200, threshold=1e-4, iters=None, active=None, cols=None):
+    def project_args(y_in, y_out, sets, rho=1.0, max_iter=200, threshold=1e-4, iters=None, active=None, cols=None,
+                     algorithm=ALG_ADMM, row_mask=None, next_stage=None):
         """isls_project_args for rows y[P,R,D]; `cols=(c0, d)` projects the coordinate block [c0, c0+d) of every row
         (the rest of the row is not touched).  sets: list of dicts kind, dim, A[dim,d] | [P,dim,d], b, par (arrays of
         the dtype of y; a leading P axis gives per-problem operands)."""
@@ -474,7 +476,12 @@ class Kernels:
             raise ValueError("project_rows: unsupported row / set dimensions")
         _dense(y_in, (P, R, D), "y_in"), _dense(y_out, (P, R, D), "y_out")
         esz = y_in.element_size() if _is_torch(y_in) else y_in.itemsize
-        a = ProjectArgs(P=P, R=R, d=d, nsets=len(sets), max_iter=int(max_iter), rho=float(rho), threshold=float(threshold))
+        a = ProjectArgs(P=P, R=R, d=d, nsets=len(sets), max_iter=int(max_iter), rho=float(rho), threshold=float(threshold),
+                        algorithm=int(algorithm))
+        if row_mask is not None:
+            if tuple(row_mask.shape) != (R,):
+                raise ValueError("row_mask must be int32[R]")
+            a.row_mask = _ptr(row_mask)
         a.y_in, a.y_out = _ptr(y_in) + c0 * esz, _ptr(y_out) + c0 * esz
         a.in_sp = a.out_sp = R * D
         a.in_sr = a.out_sr = D
@@ -495,9 +502,29 @@ class Kernels:
                 setattr(c, name + "_sp", int(arr[0].numel() if _is_torch(arr) else arr[0].size) if per else 0)
                 keep.append(arr)
         a.iters, a.active = _ptr(iters), _ptr(active)
-        a._keep = keep
-        a._spec = dict(sets=sets, rho=rho, max_iter=max_iter, threshold=threshold, cols=(c0, d))   # to rebuild elsewhere
+        if next_stage is not None:                               # a ProjectArgs applied in place to this stage's output
+            a.next = C.addressof(next_stage)
+        a._keep = keep + [row_mask, next_stage]
+        a._spec = dict(sets=sets, rho=rho, max_iter=max_iter, threshold=threshold, cols=(c0, d), algorithm=int(algorithm),
+                       row_mask=row_mask, next_stage=next_stage)                                 # to rebuild elsewhere
         return a
+
+    @staticmethod
+    def project_args_chain(y_in, y_out, stages, wrap=lambda a: a, iters=None, active=None):
+        """Descriptor of a `projections.ConvexSets` with all its stages (`.then` chain): the stages run in order, in place on
+        the first stage's output.  `wrap` moves a numpy operand to where the library expects it (device tensor / identity)."""
+        R = y_in.shape[1]
+        nxt = None
+        for k in range(len(stages) - 1, -1, -1):
+            cs = stages[k]
+            if cs.cols != stages[0].cols:
+                raise ValueError("the stages of a ConvexSets chain must act on the same coordinate block")
+            sets = [{k_: (wrap(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k_, v in st.items()} for st in cs.sets]
+            mask = cs.row_mask(R)
+            nxt = Kernels.project_args(y_in if k == 0 else y_out, y_out, sets, rho=cs.rho, max_iter=cs.max_iter, threshold=cs.threshold,
+                                       iters=iters if k == 0 else None, active=active, cols=cs.cols, algorithm=cs.algorithm,
+                                       row_mask=None if mask is None else wrap(mask), next_stage=nxt)
+        return nxt
 
     def project_rows(self, y_in, y_out, sets, stream=None, **kw):
         a = self.project_args(y_in, y_out, sets, **kw)

@@ -221,10 +221,8 @@ class Engine:
             if cs.dim != d:
                 raise ValueError(f"constraint set is defined on rows of dimension {cs.dim}, expected {d}")
             work = z(B, N, d)
-            sets = [{k: (self._t(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in st.items()}
-                    for st in cs.sets]
-            desc = capi.Kernels.project_args(work, work, sets, rho=cs.rho, max_iter=cs.max_iter, threshold=cs.threshold,
-                                             cols=cs.cols)
+            wrap = lambda a: (torch.as_tensor(a, device=self.device) if a.dtype.kind in "iu" else self._t(a))   # noqa: E731
+            desc = capi.Kernels.project_args_chain(work, work, cs.stages(), wrap=wrap)
             return desc, cs.cols[0], work
 
         self.x_sets, self.x_col0, self.x_work = device_sets(x_sets, n)

@@ -46,7 +46,8 @@ class Box:
         return expand(self.lo), expand(self.hi)
 
 
-SET_BOX, SET_SOC_UNIT, SET_SQUARE, SET_LINEAR, SET_QUADRATIC = 1, 2, 3, 4, 5     # include/isls_hip.h ISLS_SET_*
+SET_BOX, SET_SOC_UNIT, SET_SQUARE, SET_LINEAR, SET_QUADRATIC, SET_SHELL, SET_MULTILINEAR = 1, 2, 3, 4, 5, 6, 7   # include/isls_hip.h ISLS_SET_*
+ALG_ADMM, ALG_DYKSTRA, ALG_SOC = 0, 1, 2                                           # ISLS_PROJ_ALG_*
 
 
 class ConvexSets:
@@ -61,9 +62,29 @@ class ConvexSets:
     sets: list of dict(kind=SET_*, dim=, A=[dim,d], b=[dim], par=[...]) -- `par` as documented in include/isls_hip.h.
     """
 
-    def __init__(self, dim, cols, sets, rho=1.0, max_iter=200, threshold=1e-4):
+    def __init__(self, dim, cols, sets, rho=1.0, max_iter=200, threshold=1e-4, algorithm=ALG_ADMM, rows=None, then=None):
+        """algorithm: ALG_ADMM = project_set_convex, ALG_DYKSTRA = project_set_convex_dykstra (sets act on the rows themselves;
+        threshold is its `tol`), ALG_SOC = project_soc (one SOC set with A, b).  rows: indices (or a boolean mask) of the
+        time-step rows the sets apply to, the others pass through (None = all).  then: another ConvexSets applied to the
+        result (the obstacle notebook chains project_set_convex and Dykstra; one stage per group of rows otherwise)."""
         self.dim, self.cols, self.sets = int(dim), (int(cols[0]), int(cols[1])), list(sets)
         self.rho, self.max_iter, self.threshold = float(rho), int(max_iter), float(threshold)
+        self.algorithm, self.rows, self.then = int(algorithm), rows, then
+
+    def row_mask(self, R):
+        """int32 [R] mask of the rows this stage touches, or None for all rows."""
+        if self.rows is None:
+            return None
+        m = np.zeros(R, dtype=np.int32)
+        m[np.asarray(self.rows)] = 1
+        return m
+
+    def stages(self):
+        out, cur = [], self
+        while cur is not None:
+            out.append(cur)
+            cur = cur.then
+        return out
 
     @staticmethod
     def _primitive(st):
@@ -77,6 +98,12 @@ class ConvexSets:
             return lambda v: project_linear_batch(v, np.broadcast_to(par[2:], np.shape(v)), par[0], par[1])
         if kind == SET_QUADRATIC:
             return lambda v: project_quadratic_batch(v, par[0], par[1])
+        if kind == SET_SHELL:
+            return lambda v: project_quadratic_batch(v - par[2:], par[0], par[1]) + par[2:]
+        if kind == SET_MULTILINEAR:
+            q = int(par[0])
+            l, u, M = par[1:1 + q], par[1 + q:1 + 2 * q], par[1 + 2 * q:].reshape(q, -1)
+            return lambda v: np.stack([project_multilinear(r, M, l, u) for r in np.atleast_2d(v)])
         q = int(par[0])
         l, u, c = par[1], par[2], par[3:3 + q]
         W, Wi = par[3 + q:3 + q + q * q].reshape(q, q), par[3 + q + q * q:3 + q + 2 * q * q].reshape(q, q)
@@ -90,12 +117,21 @@ class ConvexSets:
     def __call__(self, flat):
         y = np.array(flat, dtype=np.float64, copy=True).reshape(-1, self.dim)
         c0, d = self.cols
-        blk = project_set_convex(y[:, c0:c0 + d].copy(), [np.asarray(s["A"], dtype=np.float64) for s in self.sets],
-                                 [np.asarray(s["b"], dtype=np.float64) for s in self.sets],
-                                 projections=[self._primitive(s) for s in self.sets], rho=self.rho,
-                                 max_iter=self.max_iter, threshold=self.threshold)
-        y[:, c0:c0 + d] = blk
-        return y.reshape(np.shape(flat))
+        sel = slice(None) if self.rows is None else np.flatnonzero(self.row_mask(y.shape[0]))
+        arg = y[sel, c0:c0 + d].copy()
+        prims = [self._primitive(s) for s in self.sets]
+        if self.algorithm == ALG_DYKSTRA:
+            blk = project_set_convex_dykstra(arg, prims, max_iter=self.max_iter, tol=self.threshold)
+        elif self.algorithm == ALG_SOC:
+            blk = project_soc(arg, np.asarray(self.sets[0]["A"], dtype=np.float64), np.asarray(self.sets[0]["b"], dtype=np.float64),
+                              rho=self.rho, max_iter=self.max_iter, tol=self.threshold)
+        else:
+            blk = project_set_convex(arg, [np.asarray(s["A"], dtype=np.float64) for s in self.sets],
+                                     [np.asarray(s["b"], dtype=np.float64) for s in self.sets], projections=prims, rho=self.rho,
+                                     max_iter=self.max_iter, threshold=self.threshold)
+        y[sel, c0:c0 + d] = np.atleast_2d(blk)
+        out = y.reshape(np.shape(flat))
+        return self.then(out) if self.then is not None else out
 
 
 def keepout_rectangles(dim, centres, sizes, angle, margin=0.5, upper=1e5, rho=10.0, max_iter=15, threshold=1e-3):
@@ -110,6 +146,20 @@ def keepout_rectangles(dim, centres, sizes, angle, margin=0.5, upper=1e5, rho=10
         par = np.concatenate([[2, a_safe[0] / 2, upper], c, W.ravel(), np.linalg.inv(W).ravel()])
         sets.append(dict(kind=SET_SQUARE, dim=dim, A=np.eye(dim), b=np.zeros(dim), par=par))
     return ConvexSets(dim, (0, dim), sets, rho=rho, max_iter=max_iter, threshold=threshold)
+
+
+def spherical_keepout(dim, centres, radii, margin=1.1, upper=1e2, q=None, admm_iter=5, admm_threshold=1e-2, dykstra_iter=50,
+                      dykstra_tol=1e-5):
+    """State constraint of notebooks/Double integrator/LQR and SLS with spherical obstacle avoidance.ipynb cell 12: keep the
+    first q coordinates (default: all) of every row outside the balls |y - c_i| < margin r_i -- project_set_convex over the
+    shells (margin r_i)^2 / 2 <= |y - c_i|^2 / 2 <= upper, then project_set_convex_dykstra over the same shells, both on the
+    device (ISLS_SET_SHELL, ISLS_PROJ_ALG_ADMM then ISLS_PROJ_ALG_DYKSTRA)."""
+    q = dim if q is None else int(q)
+    mk = lambda: [dict(kind=SET_SHELL, dim=q, A=np.eye(q), b=np.zeros(q),                       # noqa: E731
+                       par=np.concatenate([[0.5 * (margin * r) ** 2, upper], np.asarray(c, dtype=np.float64)]))
+                  for c, r in zip(centres, radii)]
+    dyk = ConvexSets(dim, (0, q), mk(), max_iter=dykstra_iter, threshold=dykstra_tol, algorithm=ALG_DYKSTRA)
+    return ConvexSets(dim, (0, q), mk(), rho=1.0, max_iter=admm_iter, threshold=admm_threshold, then=dyk)
 
 
 def chance_constraint_rows(p, upper, lower, var_x0, psi_inv, x0_pos=None, rho=10.0, max_iter=100, threshold=1e-3):

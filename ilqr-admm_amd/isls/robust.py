@@ -52,10 +52,8 @@ class ColumnSolver:
             blk = dict(xx=self.dx if key == "x" else self.du, z=z(C, B, N, d), l=z(C, B, N, d), z_prev=z(C, B, N, d),
                        work=z(B, N * d, C), proj=proj, desc=None)
             if isinstance(proj, ConvexSets):
-                sets = [{k_: (e._t(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k_, v in st.items()}
-                        for st in proj.sets]
-                blk["desc"] = capi.Kernels.project_args(blk["work"], blk["work"], sets, rho=proj.rho, max_iter=proj.max_iter,
-                                                        threshold=proj.threshold, active=e.admm_active)
+                wrap = lambda a: (torch.as_tensor(a, device=e.device) if a.dtype.kind in "iu" else e._t(a))   # noqa: E731
+                blk["desc"] = capi.Kernels.project_args_chain(blk["work"], blk["work"], proj.stages(), wrap=wrap, active=e.admm_active)
             self.blocks[key] = blk
         self.constrained = self.blocks["x"] is not None or self.blocks["u"] is not None
 

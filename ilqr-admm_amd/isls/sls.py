@@ -241,10 +241,8 @@ class SLS(Base):
                 setattr(e, blk + "_lo", lo), setattr(e, blk + "_hi", hi)
             elif isinstance(p_, ConvexSets):                    # project_set_convex over the time steps (ISLS_PROJ_SETS)
                 work = torch.zeros(B, N, d, dtype=e.dtype, device=e.device)
-                dsets = [{k: (e._t(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in st.items()}
-                         for st in p_.sets]
-                desc = capi.Kernels.project_args(work, work, dsets, rho=p_.rho, max_iter=p_.max_iter, threshold=p_.threshold,
-                                                 cols=p_.cols)
+                wrap = lambda a: (torch.as_tensor(a, device=e.device) if a.dtype.kind in "iu" else e._t(a))   # noqa: E731
+                desc = capi.Kernels.project_args_chain(work, work, p_.stages(), wrap=wrap)
                 sets.update({blk + "_sets": desc, blk + "_col0": p_.cols[0], blk + "_work": work})
         x0t = e._t(self._batched(x0, 1))
         one = torch.ones(1, dtype=e.dtype, device=e.device)

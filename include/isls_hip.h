@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ISLS_VERSION 102   /* 102: caller-owned timing context (isls_outer_args.timing), isls_reduce_convergence_table_* */
+#define ISLS_VERSION 103   /* 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
 
 #define ISLS_OK 0
 #define ISLS_ERR_ARG (-1)
@@ -252,7 +252,8 @@ int isls_rollout_ls_f32(const isls_rollout_args *a, void *stream);
  * residuals below `threshold`, or both relative changes below 1e-5), like one call of the reference.
  * P problems x R rows (<= 1024) of dimension d (<= ISLS_MAX_ROW_DIM); rows are addressed through
  * (sp, sr) element strides so that a coordinate block of a [B,N,n] state array can be projected in place.
- * nsets == 1 with sets[0].A == NULL applies the primitive directly (no iteration, dim == d).
+ * nsets == 1 with sets[0].A == NULL applies the primitive directly (no iteration, dim == d).  `algorithm` selects
+ * project_set_convex_dykstra or project_soc instead of project_set_convex; `row_mask` restricts a call to some rows.
  * ------------------------------------------------------------------------------------------- */
 #define ISLS_MAX_ROW_DIM 4
 #define ISLS_MAX_SET_DIM 5
@@ -262,6 +263,18 @@ int isls_rollout_ls_f32(const isls_rollout_args *a, void *stream);
 #define ISLS_SET_SQUARE 3    /* par: q, l, u, c[q], W[q*q], Winv[q*q]: l <= ||W(y[:q]-c)||_inf <= u    */
 #define ISLS_SET_LINEAR 4    /* par: l, u, a[dim]: l <= a'y <= u        (project_linear_batch, projections.py:30-43) */
 #define ISLS_SET_QUADRATIC 5 /* par: l, u: l <= y'y/2 <= u              (project_quadratic_batch, projections.py:91-105) */
+#define ISLS_SET_SHELL 6     /* par: l, u, c[dim]: l <= |y-c|^2/2 <= u, project_quadratic_batch(y - c, l, u) + c -- the spherical
+                                keep-out shells of notebooks/Double integrator/...spherical obstacle avoidance.ipynb cell 12  */
+#define ISLS_SET_MULTILINEAR 7 /* par: q, l[q], u[q], M[q*dim]: l <= M y <= u, y - M'(M M')^-1 (M y - clip(M y, l, u))
+                                  (project_multilinear, projections.py:46-61); q <= ISLS_MAX_SET_DIM                           */
+
+/* algorithm of isls_project_rows_* over the sets of a call */
+#define ISLS_PROJ_ALG_ADMM 0     /* project_set_convex: consensus ADMM over A_i y + b_i in C_i   (projections.py:289-374)       */
+#define ISLS_PROJ_ALG_DYKSTRA 1  /* project_set_convex_dykstra: alternating projections with corrections (projections.py:465-504);
+                                    every set acts on the row itself (A, b unused, dim == d); threshold = tol on the summed
+                                    squared correction change of a pass, at most max_iter + 1 passes                            */
+#define ISLS_PROJ_ALG_SOC 2      /* project_soc: A y + b in the second-order cone by ADMM (projections.py:163-234); one set of
+                                    kind ISLS_SET_SOC_UNIT with A [dim,d], b [dim]; threshold = tol                             */
 
 typedef struct isls_cset {
     int32_t kind, dim;          /* primitive and dimension of A y + b                               */
@@ -274,7 +287,7 @@ typedef struct isls_cset {
 typedef struct isls_project_args {
     int32_t P, R, d, nsets;
     int32_t max_iter;
-    int32_t _pad;
+    int32_t algorithm;          /* ISLS_PROJ_ALG_* (0 = project_set_convex)                         */
     double rho, threshold;
     isls_cset sets[ISLS_MAX_SETS];
     const void *y_in;           /* rows y_in[p*in_sp + r*in_sr + 0..d)   */
@@ -283,6 +296,12 @@ typedef struct isls_project_args {
     int64_t out_sp, out_sr;
     int32_t *iters;             /* [P] nullable: inner iterations run      */
     const int32_t *active;      /* [P] nullable                            */
+    const int32_t *row_mask;    /* [R] nullable, shared by the problems: rows with row_mask[r] == 0 pass through unchanged and
+                                 * take no part in the stop rule -- a constraint set that touches only some time steps (the
+                                 * state-bounds notebook projects its last two rows, each with its own set: one call per set) */
+    const struct isls_project_args *next;   /* nullable: a further stage applied in place to this stage's output (same P, R, rows,
+                                 * active; its own sets / algorithm / row_mask): project_set_convex followed by Dykstra in the
+                                 * obstacle notebook, or one stage per group of rows                                          */
 } isls_project_args;
 
 int isls_project_rows_f64(const isls_project_args *a, void *stream);

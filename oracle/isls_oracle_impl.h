@@ -770,6 +770,35 @@ static void FN(primitive)(int kind, int dim, const REAL *par, REAL *v)
             if (lo) o = v[i] * sl / nrm;
             v[i] = o;
         }
+    } else if (kind == ISLS_SET_SHELL) {      /* project_quadratic_batch(y - c, l, u) + c  (obstacle notebook, cell 12) */
+        REAL l = par[0], u = par[1], ss = 0, w[ISLS_MAX_SET_DIM];
+        const REAL *c = par + 2;
+        for (int i = 0; i < dim; ++i) { w[i] = v[i] - c[i]; ss += w[i] * w[i]; }
+        REAL val = (REAL)0.5 * ss, nrm = SQRT(ss);
+        int hi = val > u, lo = l > val;
+        REAL su = SQRT(2 * u), sl = SQRT(2 * l);
+        for (int i = 0; i < dim; ++i) {
+            REAL o = w[i];
+            if (hi) o = w[i] * su / nrm;
+            if (lo) o = w[i] * sl / nrm;
+            v[i] = o + c[i];
+        }
+    } else if (kind == ISLS_SET_MULTILINEAR) { /* project_multilinear, isls/projections.py:46-61 */
+        int q = (int)par[0];
+        const REAL *l = par + 1, *u = l + q, *Mm = u + q;
+        REAL Ax[ISLS_MAX_SET_DIM], G[ISLS_MAX_SET_DIM * ISLS_MAX_SET_DIM], Gi[ISLS_MAX_SET_DIM * ISLS_MAX_SET_DIM], mu[ISLS_MAX_SET_DIM];
+        for (int i = 0; i < q; ++i) { REAL acc = 0; for (int j = 0; j < dim; ++j) acc += Mm[i * dim + j] * v[j]; Ax[i] = acc; }
+        for (int i = 0; i < q; ++i)
+            for (int k = 0; k < q; ++k) { REAL acc = 0; for (int j = 0; j < dim; ++j) acc += Mm[i * dim + j] * Mm[k * dim + j]; G[i * q + k] = acc; }
+        if (FN(inv_lu)(G, Gi, q)) return;
+        for (int i = 0; i < q; ++i) {
+            REAL t = Ax[i];
+            if (Ax[i] > u[i]) t = u[i];
+            if (Ax[i] < l[i]) t = l[i];
+            Ax[i] = Ax[i] - t;
+        }
+        for (int i = 0; i < q; ++i) { REAL acc = 0; for (int k = 0; k < q; ++k) acc += Gi[i * q + k] * Ax[k]; mu[i] = acc; }
+        for (int j = 0; j < dim; ++j) { REAL acc = 0; for (int i = 0; i < q; ++i) acc += Mm[i * dim + j] * mu[i]; v[j] = v[j] - acc; }
     } else if (kind == ISLS_SET_SQUARE) {
         int q = (int)par[0];
         REAL l = par[1], u = par[2];
@@ -790,17 +819,133 @@ int FN(oracle_project_rows)(const isls_project_args *a)
 {
     const int P = a->P, R = a->R, d = a->d, ns = a->nsets;
     if (P < 0 || R < 1 || d < 1 || d > ISLS_MAX_ROW_DIM || ns < 1 || ns > ISLS_MAX_SETS || !a->y_in || !a->y_out) return ISLS_ERR_ARG;
-    const int direct = ns == 1 && a->sets[0].A == 0;
+    const int alg = a->algorithm;
+    const int direct = alg == ISLS_PROJ_ALG_ADMM && ns == 1 && a->sets[0].A == 0;
     const REAL rho = (REAL)a->rho, thr = (REAL)a->threshold;
+    const int32_t *mask = a->row_mask;
+    if (alg == ISLS_PROJ_ALG_SOC && (ns != 1 || a->sets[0].kind != ISLS_SET_SOC_UNIT || !a->sets[0].A || !a->sets[0].b)) return ISLS_ERR_ARG;
     int rc = ISLS_OK;
 #pragma omp parallel for schedule(dynamic)
     for (int p = 0; p < P; ++p) {
         if (a->active && !a->active[p]) continue;
         const REAL *yin = (const REAL *)a->y_in + (int64_t)p * a->in_sp;
         REAL *yout = (REAL *)a->y_out + (int64_t)p * a->out_sp;
+        if (mask)                                                  /* rows outside the mask pass through */
+            for (int r = 0; r < R; ++r)
+                if (!mask[r])
+                    for (int j = 0; j < d; ++j) yout[(int64_t)r * a->out_sr + j] = yin[(int64_t)r * a->in_sr + j];
+        if (alg == ISLS_PROJ_ALG_DYKSTRA) {                        /* project_set_convex_dykstra, isls/projections.py:465-504 */
+            REAL *uu = (REAL *)malloc(sizeof(REAL) * (size_t)R * ISLS_MAX_ROW_DIM * (1 + ISLS_MAX_SETS));
+            REAL *zz = uu + (size_t)R * ISLS_MAX_ROW_DIM;
+            for (int r = 0; r < R; ++r) {
+                for (int j = 0; j < d; ++j) uu[r * ISLS_MAX_ROW_DIM + j] = yin[(int64_t)r * a->in_sr + j];
+                for (int i = 0; i < ISLS_MAX_SETS * ISLS_MAX_ROW_DIM; ++i) zz[(size_t)r * ISLS_MAX_SETS * ISLS_MAX_ROW_DIM + i] = 0;
+            }
+            int k = 0;
+            REAL cmax = 10;
+            while (k <= a->max_iter && cmax >= thr) {              /* np.any(cI >= tol) */
+                cmax = 0;
+                for (int r = 0; r < R; ++r) {
+                    if (mask && !mask[r]) continue;
+                    REAL *u = uu + r * ISLS_MAX_ROW_DIM, *z = zz + (size_t)r * ISLS_MAX_SETS * ISLS_MAX_ROW_DIM, cI = 0;
+                    for (int s = 0; s < ns; ++s) {
+                        const REAL *par = a->sets[s].par ? (const REAL *)a->sets[s].par + (int64_t)p * a->sets[s].par_sp : 0;
+                        REAL v[ISLS_MAX_SET_DIM], prev_u[ISLS_MAX_ROW_DIM], nn = 0;
+                        for (int j = 0; j < d; ++j) { prev_u[j] = u[j]; v[j] = prev_u[j] - z[s * ISLS_MAX_ROW_DIM + j]; }
+                        FN(primitive)(a->sets[s].kind, d, par, v);
+                        for (int j = 0; j < d; ++j) {
+                            const REAL prev_z = z[s * ISLS_MAX_ROW_DIM + j];
+                            const REAL zn = v[j] - (prev_u[j] - prev_z);
+                            u[j] = v[j];
+                            z[s * ISLS_MAX_ROW_DIM + j] = zn;
+                            nn += (prev_z - zn) * (prev_z - zn);
+                        }
+                        cI += SQRT(nn) * SQRT(nn);                  /* np.linalg.norm(...)**2 */
+                    }
+                    if (cI > cmax) cmax = cI;
+                }
+                ++k;
+            }
+            for (int r = 0; r < R; ++r)
+                if (!mask || mask[r])
+                    for (int j = 0; j < d; ++j) yout[(int64_t)r * a->out_sr + j] = uu[r * ISLS_MAX_ROW_DIM + j];
+            if (a->iters) a->iters[p] = k;
+            free(uu);
+            continue;
+        }
+        if (alg == ISLS_PROJ_ALG_SOC) {                            /* project_soc, isls/projections.py:163-234 */
+            const int dm = a->sets[0].dim;
+            const REAL *A0 = (const REAL *)a->sets[0].A + (int64_t)p * a->sets[0].A_sp, *b0 = (const REAL *)a->sets[0].b + (int64_t)p * a->sets[0].b_sp;
+            REAL M[ISLS_MAX_ROW_DIM * ISLS_MAX_ROW_DIM], Li[ISLS_MAX_ROW_DIM * ISLS_MAX_ROW_DIM];
+            for (int j = 0; j < d; ++j)
+                for (int k = 0; k < d; ++k) {
+                    REAL acc = 0;
+                    for (int i = 0; i < dm; ++i) acc += A0[i * d + j] * A0[i * d + k];
+                    M[j * d + k] = (j == k ? (REAL)1 : (REAL)0) + rho * acc;
+                }
+            if (FN(inv_lu)(M, Li, d)) { rc = ISLS_ERR_ARG; continue; }
+            REAL *zz = (REAL *)malloc(sizeof(REAL) * (size_t)R * (ISLS_MAX_ROW_DIM + ISLS_MAX_SET_DIM));
+            REAL *ll = zz + (size_t)R * ISLS_MAX_ROW_DIM;
+            for (int r = 0; r < R; ++r) {
+                for (int j = 0; j < d; ++j) zz[r * ISLS_MAX_ROW_DIM + j] = yin[(int64_t)r * a->in_sr + j];
+                for (int i = 0; i < ISLS_MAX_SET_DIM; ++i) ll[r * ISLS_MAX_SET_DIM + i] = 0;
+            }
+            REAL prim_g = (REAL)1e5, dual_g = (REAL)1e5;
+            int it = 0;
+            for (int j = 0; j < a->max_iter; ++j) {
+                ++it;
+                REAL prev_p = prim_g, prev_d = dual_g, pm = 0, dmx = 0;
+                for (int r = 0; r < R; ++r) {
+                    if (mask && !mask[r]) continue;
+                    const REAL *z0 = yin + (int64_t)r * a->in_sr;
+                    REAL *z = zz + r * ISLS_MAX_ROW_DIM, *lm = ll + r * ISLS_MAX_SET_DIM;
+                    REAL x[ISLS_MAX_SET_DIM], zp[ISLS_MAX_ROW_DIM], rs[ISLS_MAX_ROW_DIM], pn = 0, dn = 0;
+                    for (int i = 0; i < dm; ++i) {
+                        REAL acc = 0;
+                        for (int k = 0; k < d; ++k) acc += A0[i * d + k] * z[k];
+                        x[i] = (acc + b0[i]) + lm[i];
+                    }
+                    FN(primitive)(ISLS_SET_SOC_UNIT, dm, 0, x);
+                    for (int k = 0; k < d; ++k) { zp[k] = z[k]; rs[k] = 0; }
+                    for (int i = 0; i < dm; ++i) {
+                        const REAL w = (-b0[i] + x[i]) - lm[i];
+                        for (int k = 0; k < d; ++k) rs[k] += A0[i * d + k] * w;
+                    }
+                    for (int i = 0; i < d; ++i) {
+                        REAL acc = 0;
+                        for (int k = 0; k < d; ++k) acc += Li[i * d + k] * (z0[k] + rho * rs[k]);
+                        z[i] = acc;
+                    }
+                    for (int i = 0; i < dm; ++i) {
+                        REAL acc = 0;
+                        for (int k = 0; k < d; ++k) acc += A0[i * d + k] * z[k];
+                        const REAL pr = (acc + b0[i]) - x[i];
+                        lm[i] += pr;
+                        pn += pr * pr;
+                    }
+                    for (int k = 0; k < d; ++k) dn += (rho * (z[k] - zp[k])) * (rho * (z[k] - zp[k]));
+                    pn = SQRT(pn); dn = SQRT(dn);
+                    if (pn > pm) pm = pn;
+                    if (dn > dmx) dmx = dn;
+                }
+                prim_g = pm; dual_g = dmx;
+                if (prim_g < thr && dual_g < thr) break;
+                if (j != a->max_iter - 1) {
+                    REAL pc = FABS(prev_p - prim_g) / (prev_p + (REAL)1e-30), dc = FABS(prev_d - dual_g) / (prev_d + (REAL)1e-30);
+                    if (pc < (REAL)1e-5 && dc < (REAL)1e-5) break;
+                }
+            }
+            for (int r = 0; r < R; ++r)
+                if (!mask || mask[r])
+                    for (int j = 0; j < d; ++j) yout[(int64_t)r * a->out_sr + j] = zz[r * ISLS_MAX_ROW_DIM + j];
+            if (a->iters) a->iters[p] = it;
+            free(zz);
+            continue;
+        }
         if (direct) {
             const REAL *par = a->sets[0].par ? (const REAL *)a->sets[0].par + (int64_t)p * a->sets[0].par_sp : 0;
             for (int r = 0; r < R; ++r) {
+                if (mask && !mask[r]) continue;
                 REAL v[ISLS_MAX_SET_DIM];
                 for (int j = 0; j < d; ++j) v[j] = yin[(int64_t)r * a->in_sr + j];
                 FN(primitive)(a->sets[0].kind, d, par, v);
@@ -850,6 +995,7 @@ int FN(oracle_project_rows)(const isls_project_args *a)
             ++it;
             REAL prev_p = prim_g, prev_d = dual_g, pm = 0, dm = 0;
             for (int r = 0; r < R; ++r) {
+                if (mask && !mask[r]) continue;
                 const REAL *x0 = yin + (int64_t)r * a->in_sr;
                 REAL *xr = x + r * ISLS_MAX_ROW_DIM, *zr = z + r * SD, *lr = lm + r * SD;
                 REAL rs[ISLS_MAX_ROW_DIM];
@@ -895,9 +1041,16 @@ int FN(oracle_project_rows)(const isls_project_args *a)
             }
         }
         for (int r = 0; r < R; ++r)
-            for (int j = 0; j < d; ++j) yout[(int64_t)r * a->out_sr + j] = x[r * ISLS_MAX_ROW_DIM + j];
+            if (!mask || mask[r])
+                for (int j = 0; j < d; ++j) yout[(int64_t)r * a->out_sr + j] = x[r * ISLS_MAX_ROW_DIM + j];
         if (a->iters) a->iters[p] = it;
         free(x);
+    }
+    if (rc == ISLS_OK && a->next) {                                /* next stage, in place on this stage's output */
+        isls_project_args nx = *a->next;
+        nx.P = P; nx.R = R; nx.d = d; nx.y_in = a->y_out; nx.y_out = a->y_out;
+        nx.in_sp = nx.out_sp = a->out_sp; nx.in_sr = nx.out_sr = a->out_sr; nx.iters = 0; nx.active = a->active;
+        rc = FN(oracle_project_rows)(&nx);
     }
     return rc;
 }

@@ -59,10 +59,7 @@ class DualKernels:
             dkw = dict(dkw, rec=self._rec)
         for blk in ("x", "u"):                                 # set descriptors hold pointers: rebuild them on the device
             if dkw.get(blk + "_sets") is not None:
-                spec, work = dkw[blk + "_sets"]._spec, dkw[blk + "_work"]
-                dsets = [{k: self._to_dev(v) for k, v in st.items()} for st in spec["sets"]]
-                dkw[blk + "_sets"] = capi.Kernels.project_args(work, work, dsets, rho=spec["rho"], max_iter=spec["max_iter"],
-                                                               threshold=spec["threshold"], cols=spec["cols"])
+                dkw[blk + "_sets"] = self._rebuild_sets(dkw[blk + "_sets"]._spec, dkw[blk + "_work"])
         getattr(self.hip, name)(*dargs, **dkw)
         torch.cuda.synchronize()
         self.calls += 1
@@ -72,6 +69,14 @@ class DualKernels:
         for k in kw:
             if isinstance(kw[k], np.ndarray):
                 self._compare(name, k, kw[k], dkw[k])
+
+    def _rebuild_sets(self, spec, work):
+        """The same descriptor (and its further stages) over device copies of the operands."""
+        nxt = self._rebuild_sets(spec["next_stage"]._spec, work) if spec.get("next_stage") is not None else None
+        dsets = [{k: self._to_dev(v) for k, v in st.items()} for st in spec["sets"]]
+        return capi.Kernels.project_args(work, work, dsets, rho=spec["rho"], max_iter=spec["max_iter"], threshold=spec["threshold"],
+                                         cols=spec["cols"], algorithm=spec.get("algorithm", 0), row_mask=self._to_dev(spec.get("row_mask")),
+                                         next_stage=nxt)
 
     def _prepare_segments(self, dargs, dkw):
         """Fresh NaN-filled operator buffers + isls_riccati_ff_prepare on the device operands of an ff call."""

@@ -594,6 +594,25 @@ def gen_projections():
     proj_state, _ = ref_keepout_projection(200, 4)
     xk = rng.standard_normal((200, 4)) * np.array([3.0, 3.0, 1.0, 1.0]) + np.array([-5.0, -5.0, 0.0, 0.0])
     out["keepout_in"], out["keepout_out"] = xk, proj_state(xk.reshape(-1).copy()).reshape(200, 4)
+    # the obstacle notebook's state projection (cell 12): project_set_convex over spherical keep-out shells, then Dykstra
+    # (appended after the draws above so that every earlier vector keeps its value)
+    centres, radii = [np.array([0.5, 0.5]), np.array([0.5, 0.2])], [0.1, 0.15]
+    lowers = [0.5 * (1.1 * r) ** 2 for r in radii]
+    shells = [lambda x, lo=lo, c=c: refproj.project_quadratic(x - c, lo, 1e2) + c for lo, c in zip(lowers, centres)]
+    pts = rng.uniform(0.0, 1.0, size=(60, 2))
+    out["shell_in"], out["shell_centres"], out["shell_lowers"] = pts, np.stack(centres), np.array(lowers)
+    out["shell_admm_out"] = refproj.project_set_convex(pts.copy(), [np.eye(2)] * 2, [np.zeros(2)] * 2, shells, max_iter=5,
+                                                       verbose=0, threshold=1e-2)
+    out["shell_dykstra_out"] = refproj.project_set_convex_dykstra(out["shell_admm_out"].copy(), shells, max_iter=50, verbose=0, tol=1e-5)
+    # project_soc with a general affine image, and project_multilinear row by row
+    As, bs = rng.standard_normal((3, 3)), rng.standard_normal(3)
+    zs_ = rng.standard_normal((30, 3)) * 2
+    out["gsoc_A"], out["gsoc_b"], out["gsoc_in"] = As, bs, zs_
+    out["gsoc_out"] = refproj.project_soc(zs_.copy(), As, bs, rho=1.0, max_iter=100, tol=1e-5)
+    Mm, lm, um = rng.standard_normal((2, 3)), np.array([-0.5, -1.0]), np.array([0.7, 0.2])
+    xm = rng.standard_normal((25, 3)) * 2
+    out["mlin_M"], out["mlin_l"], out["mlin_u"], out["mlin_in"] = Mm, lm, um, xm
+    out["mlin_out"] = np.stack([refproj.project_multilinear(r.copy(), Mm, lm, um) for r in xm])
     save("g6_projections.npz", **out)
 
 

@@ -125,10 +125,8 @@ class OracleDriver:
         if getattr(self, "_xs", None) is None:
             cs = self.x_sets
             self.x_work = np.zeros((self.B, self.N, self.n), dtype=self.dtype)
-            sets = [{k: (np.ascontiguousarray(v, dtype=self.dtype) if isinstance(v, np.ndarray) else v) for k, v in st.items()}
-                    for st in cs.sets]
-            self._xs = capi.Kernels.project_args(self.x_work, self.x_work, sets, rho=cs.rho, max_iter=cs.max_iter,
-                                                 threshold=cs.threshold, cols=cs.cols)
+            wrap = lambda a: a if a.dtype.kind in "iu" else np.ascontiguousarray(a, dtype=self.dtype)     # noqa: E731
+            self._xs = capi.Kernels.project_args_chain(self.x_work, self.x_work, cs.stages(), wrap=wrap)
         return dict(x_sets=self._xs, x_col0=self.x_sets.cols[0], x_work=self.x_work)
 
     def update(self, tol):

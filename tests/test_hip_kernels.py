@@ -358,6 +358,54 @@ def test_projection_kernels(oracle, golden):
     assert np.max(np.abs(o - h)) < 1e-4
 
 
+def test_projection_kernels_shells_dykstra_soc_multilinear(oracle, golden):
+    """SURVEY 8f-4 on the device: ISLS_SET_SHELL through project_set_convex and through Dykstra (ISLS_PROJ_ALG_DYKSTRA), the
+    two chained as the obstacle notebook does (`next`), project_soc with a general affine image (ISLS_PROJ_ALG_SOC),
+    project_multilinear (ISLS_SET_MULTILINEAR) and row masks -- against the oracle (same iteration counts, 1e-12) and against
+    the outputs of the reference's own functions (golden G6, 1e-10); fp32 against the fp32 oracle at 1e-4."""
+    import torch
+    from dual import hip_kernels
+    g = golden("g6_projections.npz")
+    rng = np.random.default_rng(3)
+    P_ = 5
+    pts = np.ascontiguousarray(np.concatenate([g["shell_in"][None], rng.uniform(0.0, 1.0, size=(P_ - 1, 60, 2))]))
+
+    def shell(dtype=np.float64):
+        return [dict(kind=capi.SET_SHELL, dim=2, A=np.eye(2, dtype=dtype), b=np.zeros(2, dtype=dtype),
+                     par=np.concatenate([[lo, 1e2], c]).astype(dtype)) for lo, c in zip(g["shell_lowers"], g["shell_centres"])]
+    o, io, h, ih = _dual_project(oracle, pts, shell(), rho=1.0, max_iter=5, threshold=1e-2)
+    assert np.array_equal(io, ih) and np.max(np.abs(o - h)) < 1e-12 and np.max(np.abs(h[0] - g["shell_admm_out"])) < 1e-10
+    o2, io2, h2, ih2 = _dual_project(oracle, h, shell(), max_iter=50, threshold=1e-5, algorithm=capi.ALG_DYKSTRA)
+    assert np.array_equal(io2, ih2) and np.max(np.abs(o2 - h2)) < 1e-12 and np.max(np.abs(h2[0] - g["shell_dykstra_out"])) < 1e-10
+    # both stages in one call (the `next` chain), as isls.projections.spherical_keepout builds it for the solvers
+    hip = hip_kernels()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()     # noqa: E731
+    import sys
+    pj = sys.modules["isls.projections"]
+    cs = pj.spherical_keepout(2, g["shell_centres"], [np.sqrt(2 * lo) / 1.1 for lo in g["shell_lowers"]])
+    yd = dev(pts)
+    desc = capi.Kernels.project_args_chain(yd, yd, cs.stages(), wrap=dev)
+    hip._call("project_rows", "f64", desc, None)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(yd.cpu().numpy() - h2)) < 1e-14
+    # general SOC image and the multilinear slab
+    soc = [dict(kind=capi.SET_SOC_UNIT, dim=3, A=np.ascontiguousarray(g["gsoc_A"]), b=np.ascontiguousarray(g["gsoc_b"]))]
+    zin = np.ascontiguousarray(np.concatenate([g["gsoc_in"][None], 2 * rng.standard_normal((2, 30, 3))]))
+    o, io, h, ih = _dual_project(oracle, zin, soc, rho=1.0, max_iter=100, threshold=1e-5, algorithm=capi.ALG_SOC)
+    assert np.array_equal(io, ih) and np.max(np.abs(o - h)) < 1e-11 and np.max(np.abs(h[0] - g["gsoc_out"])) < 1e-10
+    par = np.concatenate([[2], g["mlin_l"], g["mlin_u"], g["mlin_M"].ravel()])
+    o, _, h, _ = _dual_project(oracle, np.ascontiguousarray(g["mlin_in"][None]), [dict(kind=capi.SET_MULTILINEAR, dim=3, par=par)])
+    assert np.max(np.abs(o - h)) < 1e-13 and np.max(np.abs(h[0] - g["mlin_out"])) < 1e-11
+    # row mask: untouched rows pass through bit for bit
+    mask = np.zeros(60, dtype=np.int32)
+    mask[[3, 17, 40, 59]] = 1
+    o, io, h, ih = _dual_project(oracle, pts, shell(), rho=1.0, max_iter=5, threshold=1e-2, row_mask=mask)
+    assert np.array_equal(io, ih) and np.max(np.abs(o - h)) < 1e-12 and np.array_equal(h[:, mask == 0], pts[:, mask == 0])
+    # fp32
+    o, _, h, _ = _dual_project(oracle, pts.astype(np.float32), shell(np.float32), max_iter=50, threshold=1e-5, algorithm=capi.ALG_DYKSTRA)
+    assert np.max(np.abs(o - h)) < 1e-4
+
+
 @pytest.mark.parametrize("tag", ["d1", "d3"])
 def test_config5_sls_admm_kernels(oracle, golden, tag):
     """isls_sls_admm / isls_sls_closed_loop on the device against the oracle (fp64: every iteration, every problem) and

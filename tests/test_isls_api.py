@@ -174,6 +174,12 @@ def test_sls_lqt_admm_with_numpy_callables(golden):
     sl2.set_quadratic_cost(np.stack([np.zeros(d), [1.0, 1.0, 0.0, 0.0]]), np.stack([np.zeros((d, d)), 1e3 * np.eye(d)]), seq, 1e-4)
     with pytest.raises(NotImplementedError):
         sl2.ADMM_LQT_DP(np.zeros(d), project_x=project_state, rho_x=rho_x)
+    # the same state constraint as a device descriptor (ISLS_SET_SHELL: project_set_convex, then Dykstra): the
+    # whole ADMM iteration stays on the GPU -- batched -- and reproduces the reference's trace in its reproducible window
+    cs = projmod.spherical_keepout(d, g["centres"], g["radii"], q=x_dim)
+    xd2, ud2, Kd2, kd2, logd2 = sl2.ADMM_LQT_DP(np.zeros(d), project_x=cs, max_iter=25, rho_x=rho_x, tol=1e-4, log=True)
+    assert rel(np.stack(logd2)[:, 0], g["dp_logs"]) < 1e-8 and rel(np.stack(logd2)[:, 1], g["dp_logs"]) < 1e-8
+    assert rel(xd2[0], g["dp_x"]) < 1e-8 and rel(ud2[1], g["dp_u"]) < 1e-7
 
 
 def test_sls_replanning_and_open_loop_helpers():
