@@ -133,6 +133,21 @@ def test_sls_admm_with_state_constraints(golden):
         assert rel(np.stack(logs), g["logs"][b][:n_it]) < 1e-6
         assert rel(du, g["du"][b]) < 1e-7 and rel(phi_u[:, :1], g["phi_u"][b][:, :1]) < 1e-7
         assert phi_u.shape == g["phi_u"][b].shape and rel(phi_u, g["phi_u"][b]) < 1e-3   # tail columns: solve_sls' Woodbury chain (see G7)
+        # the same call with the constraints as device descriptors: the state projection touches two rows, each with its
+        # own set -- one stage per row (row masks + `then` chain, ISLS_PROJ_SETS): nothing leaves the GPU
+        from isls.projections import chance_constraint_rows
+        ckw = dict(rho=1e1, max_iter=20, threshold=1e-2)
+        pos = chance_constraint_rows(1, target + 0.05, target - 0.05, var_x0, psi_inv, **ckw)
+        vel = chance_constraint_rows(1, 0.0, 0.0, var_x0, psi_inv, **ckw)
+        pos.rows, vel.rows, pos.then = [N * n - 2], [N * n - 1], vel
+        dev_u = chance_constraint_rows(1, upper_u, -upper_u, var_x0, psi_inv, **ckw)
+        sl2 = isls.SLS(2, 1, N)
+        sl2.AB = [g["A"], g["B"]]
+        sl2.set_quadratic_cost(np.stack([np.zeros(n), [target, 0.0]]), np.stack([np.zeros((n, n)), 1e6 * np.eye(n)]), seq, 1e-2)
+        du2, phi2, logs2 = sl2.ADMM_SLS(project_u=dev_u, project_x=pos, max_iter=30, rho_x=g["rho_x"][b], rho_u=1e-3, alpha=1.0,
+                                        tol=1e-5, verbose=0, log=True)
+        assert len(logs2) == n_it and rel(np.stack(logs2), g["logs"][b][:n_it]) < 1e-6
+        assert rel(du2, g["du"][b]) < 1e-7 and rel(phi2[:, :1], g["phi_u"][b][:, :1]) < 1e-7
 
 
 def test_sls_lqt_admm_with_numpy_callables(golden):
