@@ -49,10 +49,12 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
     Timing *const tmg = static_cast<Timing *>(a.timing);
     int rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, ad.iters, s);
     if (rc != ISLS_OK) return rc;
+    bool ff_done = false;                                      // the gain pass ran the first feed-forward pass as well
     if (!a.skip_gain) {
         {
             ScopedTimer tm(tmg, 0, s);
-            if ((rc = launch_gain<T>(a.gain, s)) != ISLS_OK) return rc;
+            static const bool fuse_ff = [] { const char *e = getenv("ISLS_GAIN_FF"); return !e || atoi(e) != 0; }();
+            if ((rc = launch_gain<T>(a.gain, s, (fuse_ff && a.J > 0) ? &a.ff : nullptr, &ff_done)) != ISLS_OK) return rc;
         }
         if (ff_seg_enabled(a.ff.seg)) {                        // operators of the time-parallel feed-forward pass
             const isls_ff_args &f = a.ff;
@@ -68,7 +70,7 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
     const bool fuse = rollout_can_fuse_admm(a.ro, a.admm);
     bool fused = false;
     for (int j = 0; j < a.J; ++j) {
-        {
+        if (!(j == 0 && ff_done)) {
             ScopedTimer tm(tmg, 1, s);
             if ((rc = launch_ff<T>(a.ff, s)) != ISLS_OK) return rc;
         }

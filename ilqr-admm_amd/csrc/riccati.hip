@@ -34,18 +34,83 @@ struct GainP {
     T *rec;                        // nullable: packed step records [Phi | B | K | fac] for riccati_ffrec_kernel
     int32_t *status;
     const int32_t *active;
+    // FF form only: the first feed-forward pass of the outer iteration rides on the gain pass (same recursion as
+    // riccati_ffrec_kernel, sequential over the whole horizon)
+    View<T> c0x, c0u, Qr, Rr;
+    const T *xhat, *uhat, *zx, *lx, *zu, *lu;
+    T *kff;
 };
 
-template <typename T, int NX, int NU, int D>
+// 1/sqrt(a) by v_rsq + two coupled Newton steps (g -> sqrt(a), h -> 1/(2 sqrt(a))): 9 instructions against the ~30 of
+// sqrt() followed by a division (both carry range scaling the pivots of a cost Hessian never need); error 1-2 ulp.
+// a <= 0 or NaN gives NaN / inf exactly like sqrt would: the caller flags the pivot.
+__device__ __forceinline__ double rsqrt_nr(double a)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    return h + h;
+}
+__device__ __forceinline__ float rsqrt_nr(float a)
+{
+    const float y = __builtin_amdgcn_rsqf(a);
+    const float g = a * y, h = 0.5f * y;
+    const float r = fmaf(-h, g, 0.5f);
+    const float h2 = fmaf(h, r, h);
+    return h2 + h2;
+}
+// Upper Cholesky with reciprocal pivots only (the factor's diagonal itself is never used: see chol_solve)
+template <int M, typename T>
+__device__ __forceinline__ bool chol_upper_rd(const T (&A)[M][M], T (&U)[M][M], T (&rd)[M])
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        T ajj = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) ajj -= U[k][j] * U[k][j];
+        ok = ok && (ajj > T(0));
+        rd[j] = rsqrt_nr(ajj);
+        U[j][j] = T(0);
+#pragma unroll
+        for (int c = j + 1; c < M; ++c) {
+            T sacc = A[j][c];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc -= U[k][j] * U[k][c];
+            U[j][c] = sacc * rd[j];
+        }
+    }
+    return ok;
+}
+
+// MODE: ISLS_SOLVE_CHOL / ISLS_SOLVE_INV at compile time.
+// FF = true: the pass also runs the v / k recursion of the feed-forward pass (riccati_ffrec.hip: v = cx + K'cu + Phi'v,
+// k = -Quu^-1 (cu + B'v), the same sums in the same order) for the linear terms the caller's ADMM state gives -- the first
+// of the J feed-forward passes of an outer iteration rides on this pass instead of streaming the records once more.
+// Needs the packed records and time-invariant Qr / Rr rows.
+template <typename T, int NX, int NU, int D, int MODE, bool FF>
 __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
     constexpr int V_OFF = 0, AB_OFF = V_OFF + NX * NX, Q_OFF = AB_OFF + NX * W, K_OFF = Q_OFF + NU * W;
     constexpr int DUMP_OFF = K_OFF + NU * NX;              // W words that absorb the LDS writes of lanes with nothing to publish
-    constexpr int SLOT = ((DUMP_OFF + W) | 1);             // odd stride: slots start on different banks
+    // FF form: d[W] | v[NX] | cu[NU] | qu[NU] behind the dump words
+    constexpr int D_OFF = DUMP_OFF + W, VV_OFF = D_OFF + W, CU_OFF = VV_OFF + NX, QU_OFF = CU_OFF + NU;
+    constexpr int SLOT = FF ? ((QU_OFF + NU) | 1) : ((DUMP_OFF + W) | 1);   // odd stride: slots start on different banks
     constexpr int JA = (NX * NX + G - 1) / G, JB = (NX * NU + G - 1) / G, JQ = (NU * W + G - 1) / G;
     constexpr int RB = NX * NX, RK = RB + NX * NU, RFAC = RK + NU * NX, RW = rec_stride(NX, NU);   // packed record (padded stride), see riccati_ffrec.hip
     __shared__ T lds[TPW * SLOT];
+    // Image of the step's packed records, [2][TPW + 1][RW] (double buffer; slot TPW absorbs the surplus lanes): the lanes drop
+    // their words of a step here (this is also where the V update reads K from) and read the finished image back lane-linearly
+    // while the V update computes -- the wavefront's TPW records are one contiguous run of TPW*RW words, written with
+    // ceil(TPW*RW/128) fully coalesced 16-byte stores instead of W scattered 8-byte stores per lane.  The K array leaves the
+    // same way.  Two buffers: a step's image is still being read when the next step starts writing.
+    constexpr int IMG = (TPW + 1) * RW;
+    __shared__ __align__(16) T img[2 * IMG];
 
     const int lane = threadIdx.x;
     const int s = lane / G, i = lane - s * G;
@@ -55,7 +120,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     const int N = p.N;
     const int bb = valid ? b : 0;
     T *rec = lds + (inslot ? s : TPW - 1) * SLOT;
-    T *Vs = rec + V_OFF, *ABs = rec + AB_OFF, *Qs = rec + Q_OFF, *Ks = rec + K_OFF;
+    T *Vs = rec + V_OFF, *ABs = rec + AB_OFF, *Qs = rec + Q_OFF;
     const bool xl = i < NX;                                   // lane owns a row of Qxx
     const int a_row = xl ? 0 : i - NX;                        // row of [Qux Quu] for u-lanes
     const int64_t bN = (int64_t)bb * N;
@@ -67,10 +132,81 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 #pragma unroll
     for (int j = 0; j < JB; ++j) { const int e = i + G * j; dB[j] = (valid && e < NX * NU) ? AB_OFF + (e / NU) * W + NX + (e % NU) : DUMP_OFF; }
     const int qdst = (!xl && valid) ? Q_OFF + a_row * W : DUMP_OFF;          // row of [Qux Quu]
-    const int kdst = (xl && valid) ? K_OFF + i : DUMP_OFF, kstr = (xl && valid) ? NX : 0;   // column i of K
     const int vdst = (xl && valid) ? V_OFF + i * NX : DUMP_OFF;              // row i of V
 
+    // ---- global load plan: per-lane bases (trajectory, own elements) fixed for the horizon; a step adds the uniform t * stride
+    const bool has_cux = p.Cux.p != nullptr;
+    const T *pA[JA], *pB[JB];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) { const int e = i + G * j; pA[j] = p.A.at(bb, 0) + (e < NX * NX ? e : NX * NX - 1); }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) { const int e = i + G * j; pB[j] = p.Bm.at(bb, 0) + (e < NX * NU ? e : NX * NU - 1); }
+    // row i of the cost Hessian stack: [Cxx[i,:]] or [Cux[a,:] Cuu[a,:]].  Raw, unconditional loads: x-lanes never use the
+    // columns >= NX of crow; u-lanes without a Cux array read Cxx instead and the step multiplies that part by zero
+    const T *pcl = xl ? p.Cxx.at(bb, 0) + i * NX : (has_cux ? p.Cux.at(bb, 0) + a_row * NX : p.Cxx.at(bb, 0));
+    const int64_t cl_st = xl ? p.Cxx.st : (has_cux ? p.Cux.st : p.Cxx.st);
+    const T *pcr = xl ? pcl : p.Cuu.at(bb, 0) + a_row * NU;
+    const int64_t cr_st = xl ? cl_st : p.Cuu.st;
+    const int64_t a_st = p.A.st, b_st = p.Bm.st;
+    const T zmask = (xl || has_cux) ? T(1) : T(0);            // Cux absent -> 0
+    const T xmask = xl ? T(1) : T(0);
+
+    // ---- FF form: per-lane plan of the linear terms (lane i owns c_i, d_i = xhat_i - (z_i - lambda_i), v_i) ----------
+    const bool ff_hasreg = FF && (xl ? p.Qr.p != nullptr : p.Rr.p != nullptr);
+    const int ff_lim = xl ? NX : NU;
+    const T *ff_c0 = nullptr, *ff_h = nullptr, *ff_z = nullptr, *ff_l = nullptr;
+    int64_t ff_c0st = 0, ff_vst = 0, ff_hst = 0;
+    bool ff_hash = false;
+    T ff_row[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) ff_row[j] = T(0);
+    if constexpr (FF) {
+        ff_c0 = xl ? p.c0x.at(bb, 0) + i : p.c0u.at(bb, 0) + a_row;
+        ff_c0st = xl ? p.c0x.st : p.c0u.st;
+        const int dd = xl ? NX : NU;
+        const int64_t ovec = bN * dd + (xl ? i : a_row);
+        const T *ph = xl ? p.xhat : p.uhat;
+        ff_hash = ff_hasreg && ph != nullptr;
+        // lanes without a regularised block load c0 again (always a valid address) and drop the values
+        ff_h = ff_hash ? ph + ovec : ff_c0;
+        ff_z = ff_hasreg ? (xl ? p.zx : p.zu) + ovec : ff_c0;
+        ff_l = ff_hasreg ? (xl ? p.lx : p.lu) + ovec : ff_c0;
+        ff_vst = ff_hasreg ? dd : ff_c0st;
+        ff_hst = ff_hash ? ff_vst : ff_c0st;
+        if (ff_hasreg) {
+            const T *prow = xl ? p.Qr.at(bb, 0) + i * NX : p.Rr.at(bb, 0) + a_row * NU;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) ff_row[j] = (j < ff_lim) ? T(2) * prow[j < ff_lim ? j : ff_lim - 1] : T(0);   // 2 * row, exact
+        }
+    }
+    const T ff_dmask = ff_hasreg ? T(1) : T(0), ff_hmask = ff_hash ? T(1) : T(0);
+    const int ff_ddst = valid ? D_OFF + i : DUMP_OFF;                         // d_i
+    const int ff_vdst = (xl && valid) ? VV_OFF + i : DUMP_OFF;                // v_i
+    const int ff_cdst = (!xl && valid) ? CU_OFF + a_row : DUMP_OFF;           // cu_r
+    const int ff_qdst = (!xl && valid) ? QU_OFF + a_row : DUMP_OFF + 1;       // qu_r
+    const int ff_doff = D_OFF + (xl ? 0 : NX);
+    // c_i = c0_i + 2 * (row of Qr / Rr) . d      (isls/sls.py:132-137; riccati_ffrec.hip reg_grad: c0 + 2 * sum, the factor
+    // folded into the row -- a power of two, so every product and the sum round exactly as there)
+    auto ff_grad = [&](T c0v) -> T {
+        T sacc = T(0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) sacc += ff_row[j] * rec[ff_doff + j];   // j >= lim: zero row entry times a neighbour word
+        return c0v + sacc;
+    };
+
     // ---- terminal step: K[N-1] = 0 (isls.py:245), V = Cxx[N-1] (isls.py:251/257) -----------------
+    if constexpr (FF) {                                        // v = cx[N-1], k[N-1] = 0
+        // ff_grad multiplies words behind a u-lane's d block by zero row entries: they must be finite from the start
+        for (int e = i; e < SLOT - D_OFF; e += G) rec[D_OFF + e] = T(0);
+        slot_sync();
+        const int64_t tl = N - 1;
+        const T c0v = ff_c0[tl * ff_c0st], hv = ff_h[tl * ff_hst], zv = ff_z[tl * ff_vst], lv = ff_l[tl * ff_vst];
+        rec[ff_ddst] = ff_hasreg ? (ff_hash ? hv : T(0)) - (zv - lv) : T(0);
+        slot_sync();
+        rec[ff_vdst] = ff_grad(c0v);
+        if (valid && !xl) p.kff[(bN + tl) * NU + a_row] = T(0);
+        slot_sync();
+    }
     {
         T r[JA];
         coop_load<NX * NX, G>(p.Cxx.at(bb, N - 1), r, i, valid);
@@ -91,31 +227,95 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     }
 
     // ---- register ring: operands of D steps in flight ------------------------------------------------
-    const bool has_cux = p.Cux.p != nullptr;
     struct Stage {
         T ra[JA], rb[JB], crow[W];
+        T c0, hv, zv, lv;                                      // FF form
     };
     Stage ring[D];
-    auto fetch = [&](int t, Stage &g) {
-        coop_load<NX * NX, G>(p.A.at(bb, t), g.ra, i, valid);
-        coop_load<NX * NU, G>(p.Bm.at(bb, t), g.rb, i, valid);
-        // row i of the cost Hessian stack: [Cxx[i,:]] or [Cux[a,:] Cuu[a,:]]
-        // Raw, unconditional loads through per-lane pointers (no branch, no arithmetic on the results here).
-        // x-lanes: columns >= NX of crow are never used; u-lanes without a Cux array read Cxx instead and
-        // the step zeroes that part when it consumes the row.
-        const T *cl = xl ? p.Cxx.at(bb, t) + i * NX : (has_cux ? p.Cux.at(bb, t) + a_row * NX : p.Cxx.at(bb, t));
-        const T *cr = xl ? cl : p.Cuu.at(bb, t) + a_row * NU;
+    auto fetch = [&](int tq, Stage &g) {
+        const int t = __builtin_amdgcn_readfirstlane(tq);      // uniform: the offsets below are scalar arithmetic
+        const int64_t oa = (int64_t)t * a_st, ob = (int64_t)t * b_st;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) g.ra[j] = pA[j][oa];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) g.rb[j] = pB[j][ob];
+        const T *cl = pcl + (int64_t)t * cl_st, *cr = pcr + (int64_t)t * cr_st;
 #pragma unroll
         for (int j = 0; j < NX; ++j) g.crow[j] = cl[j];
 #pragma unroll
         for (int j = 0; j < NU; ++j) g.crow[NX + j] = cr[j];
+        if constexpr (FF) {
+            g.c0 = ff_c0[(int64_t)t * ff_c0st];
+            g.hv = ff_h[(int64_t)t * ff_hst];
+            g.zv = ff_z[(int64_t)t * ff_vst];
+            g.lv = ff_l[(int64_t)t * ff_vst];
+        }
     };
 #pragma unroll
     for (int d = 0; d < D; ++d)
         fetch(N - 2 - d > 0 ? N - 2 - d : 0, ring[d]);          // unconditional (clamped): exact vmcnt bookkeeping
     bool pd_ok = true;
+    // where a lane's W words of the packed record go: x-lane i -> column i of Phi (stride NX) then of K (stride NX);
+    // u-lane r -> column r of B (stride NU) then row r of fac: 9 lanes x 9 words = the whole 81-word record at n=6, m=3
+    const int r_b1 = s * RW + (xl ? i : RB + a_row), r_s1 = xl ? NX : NU;
+    const int r_b2 = s * RW + (xl ? RK + i : RFAC + a_row * NU), r_s2 = xl ? NX : 1;
+    // lane-linear plan of the image's way out: 16-byte pair q = lane + 64 j of the TPW*RW record words (the last pair again
+    // for surplus lanes: same words to the same address), and pair / word e of the slots' K blocks for the K array
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    constexpr int NPAIR = TPW * RW / 2, JP = (NPAIR + kWave - 1) / kWave;
+    constexpr bool KPAIRS = (NU * NX) % 2 == 0 && RK % 2 == 0;
+    constexpr int KU = KPAIRS ? NU * NX / 2 : NU * NX, JK = (TPW * KU + kWave - 1) / kWave;   // K pieces per slot / loads per lane
+    int kso[JK];                                               // image word of the lane's K piece, -1: none
+    int64_t kgo[JK];                                           // its word in the K array at t = 0
+#pragma unroll
+    for (int j = 0; j < JK; ++j) {
+        const int e = lane + kWave * j, sl = e / KU, pc = e - sl * KU;
+        const int bk = blockIdx.x * TPW + sl;
+        const bool ok = sl < TPW && bk < p.B && (p.active == nullptr || p.active[bk] != 0);
+        kso[j] = ok ? sl * RW + RK + pc * (KPAIRS ? 2 : 1) : -1;
+        kgo[j] = ok ? (int64_t)bk * N * (NU * NX) + pc * (KPAIRS ? 2 : 1) : 0;
+    }
+    int fw[JP];                                                // image word of the lane's j-th record pair
+#pragma unroll
+    for (int j = 0; j < JP; ++j) { const int pq = lane + kWave * j; fw[j] = 2 * (pq < NPAIR ? pq : NPAIR - 1); }
+    T *const recg = p.rec ? p.rec + (int64_t)blockIdx.x * N * (TPW * RW) : nullptr;   // the wavefront's records, step 0
 
-    auto step = [&](int t, Stage &g) {
+    // The image of a step is read back into fl / fk behind its sync (c) and leaves for HBM during the NEXT step, one store
+    // between two blocks of that step's arithmetic: a wavefront waits while a store's data drains (the CU moves ~7-16 B per
+    // clock), so stores issued back to back are paid in full, spread out they overlap with the arithmetic.
+    V2 fl[JP], fk[JK];
+    T fk1[JK];
+    auto send = [&](int tq, int j) {                           // j-th of the JP + JK stores of step tq's image
+        if (j < JP) {
+            if (recg) *reinterpret_cast<V2 *>(recg + (int64_t)tq * (TPW * RW) + fw[j < JP ? j : 0]) = fl[j < JP ? j : 0];
+        } else if (j < JP + JK) {
+            const int jj = j - JP < JK ? (j - JP >= 0 ? j - JP : 0) : 0;
+            if (kso[jj] >= 0) {
+                T *dk = p.K + kgo[jj] + (int64_t)tq * (NU * NX);
+                if constexpr (KPAIRS) *reinterpret_cast<V2 *>(dk) = fk[jj];
+                else *dk = fk1[jj];
+            }
+        }
+    };
+    // the JP + JK stores take evenly spaced places among the 3 NX blocks of the step's three accumulation loops
+    constexpr int NSEND = JP + JK, NPOS = 3 * NX;
+    static_assert(NSEND <= NPOS, "at most one store per block");
+    auto send_at = [&](int tq, auto POS) {
+        constexpr int pos = decltype(POS)::value;
+#ifndef ISLS_GAIN_EXP_NOFLUSH
+        static_for<NSEND>([&](auto JJ) {
+            constexpr int j = decltype(JJ)::value;
+            if constexpr ((j * NPOS) / NSEND == pos) {
+                __builtin_amdgcn_sched_barrier(0);
+                send(tq, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+#endif
+    };
+    auto step = [&](int t, Stage &g, int q, auto FLUSH) {
+        constexpr bool flush_prev = decltype(FLUSH)::value;
+        T *imq = img + q * IMG;
         // stage [A_t B_t] into the record: row k = [A[k,:] B[k,:]]
 #pragma unroll
         for (int j = 0; j < JA; ++j) rec[dA[j]] = g.ra[j];
@@ -123,46 +323,67 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         for (int j = 0; j < JB; ++j) rec[dB[j]] = g.rb[j];
         T c_now[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) c_now[j] = (j < NX && !xl && !has_cux) ? T(0) : g.crow[j];   // Cux absent -> 0
+        for (int j = 0; j < W; ++j) c_now[j] = g.crow[j];
+        T ff_c0v = T(0);
+        if constexpr (FF) {
+            rec[ff_ddst] = ff_dmask * (ff_hmask * g.hv - (g.zv - g.lv));
+            ff_c0v = g.c0;
+        }
         slot_sync();                                          // (a) ABs, Vs visible to the slot
         fetch(t - D > 0 ? t - D : 0, g);                       // refill this ring entry (clamped, unconditional)
 
         // (1) S = row i of [A B]'V
-        T S[NX];
+        T S[NX], colv[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) S[j] = T(0);
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
+        static_for<NX>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
             const T col = ABs[k * W + i];
+            colv[k] = col;
 #pragma unroll
             for (int j = 0; j < NX; ++j) S[j] += col * Vs[k * NX + j];
+            if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, k>{});
+        });
+        // FF form: c_i, and the u-lanes' qu_r = cu_r + (B'v)_r from their column of B
+        T ff_ci = T(0), ff_v[NX];
+        if constexpr (FF) {
+            ff_ci = ff_grad(ff_c0v);
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                ff_v[k] = rec[VV_OFF + k];
+                acc += colv[k] * ff_v[k];
+            }
+            rec[ff_cdst] = ff_ci;
+            rec[ff_qdst] = ff_ci + acc;
         }
         // (2) M = C_row + S [A B]      (Qxx = Cxx + (A'V)A etc., isls.py:288-290)
         T M[W];
 #pragma unroll
         for (int c = 0; c < W; ++c) M[c] = T(0);
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
+        static_for<NX>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
 #pragma unroll
             for (int c = 0; c < W; ++c) M[c] += S[k] * ABs[k * W + c];
-        }
+            if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, NX + k>{});
+        });
 #pragma unroll
-        for (int c = 0; c < W; ++c) M[c] = c_now[c] + M[c];
+        for (int c = 0; c < W; ++c) M[c] = (c < NX) ? fma(c_now[c], zmask, M[c]) : c_now[c] + M[c];   // one rounding either way
         // (3) u-lanes publish their row of [Qux Quu] (x-lanes write the dump words)
 #pragma unroll
         for (int c = 0; c < W; ++c) rec[qdst + c] = M[c];
         slot_sync();                                          // (b)
 
-        // (4) factor Quu (redundantly in every lane), solve for column i of K
+        // (4) factor Quu (redundantly in every lane), solve for column i of K (u-lanes: a zero right-hand side, K column 0)
         T Quu[NU][NU], U[NU][NU], rd[NU], rhs[NU], Kc[NU], inv[NU][NU];
 #pragma unroll
         for (int r = 0; r < NU; ++r) {
 #pragma unroll
             for (int c = 0; c < NU; ++c) { Quu[r][c] = Qs[r * W + NX + c]; U[r][c] = T(0); inv[r][c] = T(0); }
-            rhs[r] = Qs[r * W + (xl ? i : 0)];                 // column i of Qux
+            rhs[r] = Qs[r * W + (xl ? i : 0)] * xmask;         // column i of Qux
         }
-        pd_ok = chol_upper<NU>(Quu, U, rd) && pd_ok;
-        if (p.mode == ISLS_SOLVE_CHOL) {
+        pd_ok = chol_upper_rd<NU>(Quu, U, rd) && pd_ok;
+        if constexpr (MODE == ISLS_SOLVE_CHOL) {
             T x[NU];
             chol_solve<NU>(U, rd, rhs, x);                     // sol = -solve(Quu, Qux)  (isls.py:296)
 #pragma unroll
@@ -186,70 +407,98 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
             }
         }
         const int64_t o = bN + t;
-        // packed records are blocked by wavefront, [block][t][slot][RW]: the TPW trajectories of a workgroup write (and the
-        // feed-forward pass reads) one contiguous burst per step
-        const int64_t orec = ((int64_t)blockIdx.x * N + t) * TPW + s;
+        // the lane's column of [Phi | B]: x-lane i -> Phi[:, i] = A[:, i] + B K[:, i]; u-lane r -> B[:, r] (its K column is zero)
+        T phc[NX];
+        static_for<NX>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            T ph = colv[k];
 #pragma unroll
-        for (int r = 0; r < NU; ++r) rec[kdst + r * kstr] = Kc[r];
-        if (xl && valid) {
+            for (int r = 0; r < NU; ++r) ph += ABs[k * W + NX + r] * Kc[r];
+            phc[k] = ph;
+            if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, 2 * NX + k>{});
+        });
+        // the cached factor's row a_row (identical values in every lane; the row is picked by selects); x-lanes carry their
+        // column of K in the same registers
+        T tail[NU];
 #pragma unroll
-            for (int r = 0; r < NU; ++r) p.K[(o * NU + r) * NX + i] = Kc[r];
+        for (int c = 0; c < NU; ++c) {
+            T v = xl ? Kc[c] : ((MODE == ISLS_SOLVE_CHOL) ? (c == 0 ? rd[0] : U[0][c]) : inv[0][c]);
+#pragma unroll
+            for (int r = 1; r < NU; ++r) {
+                const T vr = (MODE == ISLS_SOLVE_CHOL) ? ((c == r) ? rd[r] : (c > r ? U[r][c] : T(0))) : inv[r][c];
+                v = (a_row == r) ? vr : v;
+            }
+            tail[c] = v;
         }
-        if (valid && p.Qux) {
-            // cooperative store of [Qux Quu] rows (skipped when the caller only wants K, fac and the packed records: every
-            // consumer of Qux / Quu then reads the records instead)
+        if constexpr (FF) {
+            T qu[NU], cuv[NU], kt[NU];
 #pragma unroll
-            for (int j = 0; j < JQ; ++j) {
-                const int e = i + G * j;
-                if (e < NU * W) {
-                    const int r = e / W, c = e % W;
-                    const T v = Qs[e];
-                    if (c < NX) p.Qux[(o * NU + r) * NX + c] = v;
-                    else p.Quu[(o * NU + r) * NU + (c - NX)] = v;
+            for (int r = 0; r < NU; ++r) { cuv[r] = rec[CU_OFF + r]; qu[r] = rec[QU_OFF + r]; }
+            if constexpr (MODE == ISLS_SOLVE_CHOL) {
+                T x[NU];
+                chol_solve<NU>(U, rd, qu, x);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) kt[r] = -x[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+                    T a2 = T(0);
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) a2 += inv[r][c] * qu[c];
+                    kt[r] = -a2;
                 }
             }
+            T kv = kt[0];
+#pragma unroll
+            for (int r = 1; r < NU; ++r) kv = (a_row == r) ? kt[r] : kv;
+            if (valid && !xl) p.kff[o * NU + a_row] = kv;
+            // v_i = (cx_i + (Phi'v)_i) + (K'cu)_i
+            T acc = T(0), kcu = T(0);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) acc += phc[k] * ff_v[k];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) kcu += Kc[r] * cuv[r];
+            rec[ff_vdst] = (ff_ci + acc) + kcu;                // read again only after the next (a)
         }
+        // the lane's W words of the record image (unconditional: surplus lanes own the image's spare slot)
+#pragma unroll
+        for (int k = 0; k < NX; ++k) imq[r_b1 + k * r_s1] = phc[k];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) imq[r_b2 + c * r_s2] = tail[c];
         if (valid) {
-            // factor: row i written by lane i < NU (the values are identical in every lane; the row is picked by selects)
-            if (i < NU) {
+            if (p.Qux) {
+                // cooperative store of [Qux Quu] rows and the factor (skipped when the caller only wants K and the packed
+                // records: every consumer of Qux / Quu / fac then reads the records instead)
 #pragma unroll
-                for (int c = 0; c < NU; ++c) {
-                    T v = T(0);
-#pragma unroll
-                    for (int r = 0; r < NU; ++r) {
-                        const T vr = (p.mode == ISLS_SOLVE_CHOL) ? ((c == r) ? rd[r] : (c > r ? U[r][c] : T(0))) : inv[r][c];
-                        v = (i == r) ? vr : v;
-                    }
-                    if (p.fac) p.fac[(o * NU + i) * NU + c] = v;
-                    if (p.rec) p.rec[orec * RW + RFAC + i * NU + c] = v;
-                }
-            }
-            // packed record of the feed-forward pass (riccati_ffrec.hip): closed-loop matrix Phi = A + B K (lane i owns
-            // column i, like its column of K), then B, K as they are
-            if (p.rec) {
-                T *ro = p.rec + orec * RW;
-                if (xl) {
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) {
-                        T ph = ABs[k * W + i];
-#pragma unroll
-                        for (int r = 0; r < NU; ++r) ph += ABs[k * W + NX + r] * Kc[r];
-                        ro[k * NX + i] = ph;
-                    }
-#pragma unroll
-                    for (int r = 0; r < NU; ++r) ro[RK + r * NX + i] = Kc[r];
-                }
-#pragma unroll
-                for (int j = 0; j < JB; ++j) {
+                for (int j = 0; j < JQ; ++j) {
                     const int e = i + G * j;
-                    if (e < NX * NU) ro[RB + e] = ABs[(e / NU) * W + NX + (e % NU)];
+                    if (e < NU * W) {
+                        const int r = e / W, c = e % W;
+                        const T v = Qs[e];
+                        if (c < NX) p.Qux[(o * NU + r) * NX + c] = v;
+                        else p.Quu[(o * NU + r) * NU + (c - NX)] = v;
+                    }
+                }
+                if (!xl) {
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) p.fac[(o * NU + a_row) * NU + c] = tail[c];
                 }
             }
         }
-        slot_sync();                                          // (c) Ks visible
+        slot_sync();                                          // (c) the image (K among it) visible
+        const T *Ks = imq + s * RW + RK;
+        // the finished image goes back into registers lane-linearly (unconditional reads, issued ahead of the V update whose
+        // arithmetic covers their latency) and leaves for HBM behind it
+#pragma unroll
+        for (int j = 0; j < JP; ++j) fl[j] = *reinterpret_cast<const V2 *>(imq + fw[j]);
+#pragma unroll
+        for (int j = 0; j < JK; ++j) {
+            if constexpr (KPAIRS) fk[j] = *reinterpret_cast<const V2 *>(imq + (kso[j] >= 0 ? kso[j] : 0));
+            else fk1[j] = imq[kso[j] >= 0 ? kso[j] : 0];
+        }
 
         // (5) V row i = Qxx + (K'Quu)K + Qux'K + K'Qux   (isls.py:300 / sls.py:153); u-lanes run the same instructions
-        // on their clamped column and write the dump words
+        // on their zero column and write the dump words
         {
             T Wr[NU];
 #pragma unroll
@@ -269,7 +518,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                     t2 += rhs[r] * kj;                         // Qux' K
                     t3 += Kc[r] * Qs[r * W + j];               // K' Qux
                 }
-                const T vn = (p.mode == ISLS_SOLVE_CHOL) ? ((M[j] + t1) + t2) + t3 : ((M[j] + t2) + t3) + t1;
+                const T vn = (MODE == ISLS_SOLVE_CHOL) ? ((M[j] + t1) + t2) + t3 : ((M[j] + t2) + t3) + t1;
                 rec[vdst + j] = vn;
             }
         }
@@ -277,20 +526,36 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 
     // full groups of D steps run branch-free (every VMEM op of the steady state is unconditional, so the
     // compiler's vmcnt bookkeeping is exact and D steps of loads really stay in flight); then the remainder
+    static_assert(D == 2, "the record image is double-buffered by ring position");
     int tb = N - 2;
-    for (; tb - (D - 1) >= 0; tb -= D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) step(tb - d, ring[d]);
+    int tlast = -1;
+    if (tb >= 0) {                                             // first step: no image to send yet
+        step(tb, ring[0], 0, std::false_type{});
+        tlast = tb;
+        --tb;
     }
+    for (; tb - (D - 1) >= 0; tb -= D) {
+        step(tb, ring[1], 1, std::true_type{});
+        step(tb - 1, ring[0], 0, std::true_type{});
+        tlast = tb - 1;
+    }
+    if (tb >= 0) {                                             // one more step (tb == 0)
+        step(tb, ring[1], 1, std::true_type{});
+        tlast = tb;
+    }
+#ifndef ISLS_GAIN_EXP_NOFLUSH
+    if (tlast >= 0) {                                          // the last step's image
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (tb - d >= 0) step(tb - d, ring[d]);
+        for (int j = 0; j < JP + JK; ++j) send(tlast, j);
+    }
+#endif
     if (valid && i == 0 && !pd_ok && p.status) atomicOr(&p.status[b], ISLS_ST_NOT_PD);
 }
 
 template <typename T>
-int launch_gain(const isls_gain_args &a, hipStream_t s)
+int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, bool *did_ff)
 {
+    if (did_ff) *did_ff = false;
     if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.Cxx.p || !a.Cuu.p || !a.K) return ISLS_ERR_ARG;
     // Quu, fac, Qux: all three or none; none only with records (every consumer then reads those)
     if ((!a.Quu || !a.Qux || !a.fac) && (!a.rec || a.Quu || a.Qux || a.fac)) return ISLS_ERR_ARG;
@@ -301,18 +566,40 @@ int launch_gain(const isls_gain_args &a, hipStream_t s)
     p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.Cxx = View<T>(a.Cxx); p.Cuu = View<T>(a.Cuu); p.Cux = View<T>(a.Cux);
     p.K = (T *)a.K; p.Quu = (T *)a.Quu; p.fac = (T *)a.fac; p.Qux = (T *)a.Qux; p.rec = (T *)a.rec;
     p.status = a.status; p.active = a.active;
-#define CALL(NX_, NU_)                                                                                     \
-    {                                                                                                      \
-        constexpr int TPW = kWave / (NX_ + NU_);                                                           \
-        const int grid = (a.B + TPW - 1) / TPW;                                                            \
-        hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth>), dim3(grid), dim3(64), 0, s, p);  \
+    p.xhat = p.uhat = p.zx = p.lx = p.zu = p.lu = nullptr; p.kff = nullptr;
+    // the first feed-forward pass rides along when it would run on this pass's records with time-invariant Qr / Rr rows
+    const bool with_ff = ff && a.rec && ff->rec == a.rec && ff->k && ff->B == a.B && ff->N == a.N && ff->n == a.n && ff->m == a.m &&
+                         ff->solve_mode == a.solve_mode && ff->active == a.active && ff->c0x.p && ff->c0u.p &&
+                         (!ff->Qr.p || ff->Qr.st == 0) && (!ff->Rr.p || ff->Rr.st == 0) && (!ff->Qr.p || (ff->zx && ff->lx)) &&
+                         (!ff->Rr.p || (ff->zu && ff->lu));
+    if (with_ff) {
+        p.c0x = View<T>(ff->c0x); p.c0u = View<T>(ff->c0u); p.Qr = View<T>(ff->Qr); p.Rr = View<T>(ff->Rr);
+        p.xhat = (const T *)ff->xhat; p.uhat = (const T *)ff->uhat;
+        p.zx = (const T *)ff->zx; p.lx = (const T *)ff->lx; p.zu = (const T *)ff->zu; p.lu = (const T *)ff->lu;
+        p.kff = (T *)ff->k;
+    }
+#define LAUNCH_G(NX_, NU_, MODE_, FF_) \
+    hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_>), dim3(grid), dim3(64), 0, s, p)
+#define CALL(NX_, NU_)                                                                      \
+    {                                                                                       \
+        constexpr int TPW = kWave / (NX_ + NU_);                                            \
+        const int grid = (a.B + TPW - 1) / TPW;                                             \
+        if (a.solve_mode == ISLS_SOLVE_CHOL) {                                              \
+            if (with_ff) LAUNCH_G(NX_, NU_, ISLS_SOLVE_CHOL, true);                         \
+            else LAUNCH_G(NX_, NU_, ISLS_SOLVE_CHOL, false);                                \
+        } else {                                                                            \
+            if (with_ff) LAUNCH_G(NX_, NU_, ISLS_SOLVE_INV, true);                          \
+            else LAUNCH_G(NX_, NU_, ISLS_SOLVE_INV, false);                                 \
+        }                                                                                   \
     }
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
+#undef LAUNCH_G
+    if (did_ff) *did_ff = with_ff;
     return check_launch();
 }
-template int launch_gain<double>(const isls_gain_args &, hipStream_t);
-template int launch_gain<float>(const isls_gain_args &, hipStream_t);
+template int launch_gain<double>(const isls_gain_args &, hipStream_t, const isls_ff_args *, bool *);
+template int launch_gain<float>(const isls_gain_args &, hipStream_t, const isls_ff_args *, bool *);
 
 
 }  // namespace isls
