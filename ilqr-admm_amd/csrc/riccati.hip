@@ -92,7 +92,13 @@ __device__ __forceinline__ bool chol_upper_rd(const T (&A)[M][M], T (&U)[M][M], 
 // k = -Quu^-1 (cu + B'v), the same sums in the same order) for the linear terms the caller's ADMM state gives -- the first
 // of the J feed-forward passes of an outer iteration rides on this pass instead of streaming the records once more.
 // Needs the packed records and time-invariant Qr / Rr rows.
-template <typename T, int NX, int NU, int D, int MODE, bool FF>
+// REC: the packed records are written; ARR: the Quu / fac / Qux arrays are (the single-call form).
+// Every memory instruction of the step loop is unconditional -- a conditional one makes the compiler's vmcnt bookkeeping
+// fall back to vmcnt(0), which drains the stores in flight at every wait for the register ring.  Lanes without a
+// trajectory of their own are therefore exact copies: surplus lanes of the wavefront repeat its last lane, and a slot whose
+// trajectory is past the batch or inactive shadows the first valid trajectory of the wavefront (same loads, same
+// arithmetic, same stores to the same addresses; only the record image keeps the slot's own place).
+template <typename T, int NX, int NU, int D, int MODE, bool FF, bool REC, bool ARR>
 __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     constexpr int JA = (NX * NX + G - 1) / G, JB = (NX * NU + G - 1) / G, JQ = (NU * W + G - 1) / G;
     constexpr int RB = NX * NX, RK = RB + NX * NU, RFAC = RK + NU * NX, RW = rec_stride(NX, NU);   // packed record (padded stride), see riccati_ffrec.hip
     __shared__ T lds[TPW * SLOT];
-    // Image of the step's packed records, [2][TPW + 1][RW] (double buffer; slot TPW absorbs the surplus lanes): the lanes drop
+    // Image of the step's packed records, [2][TPW + 1][RW] (double buffer): the lanes drop
     // their words of a step here (this is also where the V update reads K from) and read the finished image back lane-linearly
     // while the V update computes -- the wavefront's TPW records are one contiguous run of TPW*RW words, written with
     // ceil(TPW*RW/128) fully coalesced 16-byte stores instead of W scattered 8-byte stores per lane.  The K array leaves the
@@ -113,13 +119,17 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     __shared__ __align__(16) T img[2 * IMG];
 
     const int lane = threadIdx.x;
-    const int s = lane / G, i = lane - s * G;
+    const bool inslot = lane / G < TPW;
+    const int s = inslot ? lane / G : TPW - 1, i = inslot ? lane - (lane / G) * G : G - 1;   // surplus lanes repeat the last lane
     const int b = blockIdx.x * TPW + s;
-    const bool inslot = s < TPW;
-    const bool valid = inslot && b < p.B && (p.active == nullptr || p.active[b] != 0);
+    const bool valid = b < p.B && (p.active == nullptr || p.active[b] != 0);
+    const unsigned long long vmask = __ballot(valid);
+    if (vmask == 0ull) return;                                 // nothing to do for this wavefront
+    const int vlane = __builtin_ctzll(vmask);                  // a lane of the first valid slot
+    const int bsh = __builtin_amdgcn_readlane(b, vlane), ssh = __builtin_amdgcn_readlane(s, vlane);
     const int N = p.N;
-    const int bb = valid ? b : 0;
-    T *rec = lds + (inslot ? s : TPW - 1) * SLOT;
+    const int bb = valid ? b : bsh;
+    T *rec = lds + s * SLOT;
     T *Vs = rec + V_OFF, *ABs = rec + AB_OFF, *Qs = rec + Q_OFF;
     const bool xl = i < NX;                                   // lane owns a row of Qxx
     const int a_row = xl ? 0 : i - NX;                        // row of [Qux Quu] for u-lanes
@@ -128,11 +138,11 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     // publish point at the dump words, so no ds_write of the step loop sits behind an exec-mask branch
     int dA[JA], dB[JB];
 #pragma unroll
-    for (int j = 0; j < JA; ++j) { const int e = i + G * j; dA[j] = (valid && e < NX * NX) ? AB_OFF + (e / NX) * W + (e % NX) : DUMP_OFF; }
+    for (int j = 0; j < JA; ++j) { const int e = i + G * j; dA[j] = (e < NX * NX) ? AB_OFF + (e / NX) * W + (e % NX) : DUMP_OFF; }
 #pragma unroll
-    for (int j = 0; j < JB; ++j) { const int e = i + G * j; dB[j] = (valid && e < NX * NU) ? AB_OFF + (e / NU) * W + NX + (e % NU) : DUMP_OFF; }
-    const int qdst = (!xl && valid) ? Q_OFF + a_row * W : DUMP_OFF;          // row of [Qux Quu]
-    const int vdst = (xl && valid) ? V_OFF + i * NX : DUMP_OFF;              // row i of V
+    for (int j = 0; j < JB; ++j) { const int e = i + G * j; dB[j] = (e < NX * NU) ? AB_OFF + (e / NU) * W + NX + (e % NU) : DUMP_OFF; }
+    const int qdst = !xl ? Q_OFF + a_row * W : DUMP_OFF;                     // row of [Qux Quu]
+    const int vdst = xl ? V_OFF + i * NX : DUMP_OFF;                         // row i of V
 
     // ---- global load plan: per-lane bases (trajectory, own elements) fixed for the horizon; a step adds the uniform t * stride
     const bool has_cux = p.Cux.p != nullptr;
@@ -180,10 +190,11 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         }
     }
     const T ff_dmask = ff_hasreg ? T(1) : T(0), ff_hmask = ff_hash ? T(1) : T(0);
-    const int ff_ddst = valid ? D_OFF + i : DUMP_OFF;                         // d_i
-    const int ff_vdst = (xl && valid) ? VV_OFF + i : DUMP_OFF;                // v_i
-    const int ff_cdst = (!xl && valid) ? CU_OFF + a_row : DUMP_OFF;           // cu_r
-    const int ff_qdst = (!xl && valid) ? QU_OFF + a_row : DUMP_OFF + 1;       // qu_r
+    const int ff_ddst = D_OFF + i;                                            // d_i
+    const int ff_vdst = xl ? VV_OFF + i : DUMP_OFF;                           // v_i
+    const int ff_cdst = !xl ? CU_OFF + a_row : DUMP_OFF;                      // cu_r
+    const int ff_qdst = !xl ? QU_OFF + a_row : DUMP_OFF + 1;                  // qu_r
+    const int ff_ku = xl ? i % NU : a_row;                                    // the entry of k_t this lane stores (x-lanes: a copy)
     const int ff_doff = D_OFF + (xl ? 0 : NX);
     // c_i = c0_i + 2 * (row of Qr / Rr) . d      (isls/sls.py:132-137; riccati_ffrec.hip reg_grad: c0 + 2 * sum, the factor
     // folded into the row -- a power of two, so every product and the sum round exactly as there)
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     {
         T r[JA];
         coop_load<NX * NX, G>(p.Cxx.at(bb, N - 1), r, i, valid);
-        coop_put<NX * NX, G>(Vs, r, i, valid);
+        coop_put<NX * NX, G>(Vs, r, i, true);
         if (valid) {
             const int64_t o = bN + (N - 1);
 #pragma unroll
@@ -265,20 +276,23 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     constexpr int NPAIR = TPW * RW / 2, JP = (NPAIR + kWave - 1) / kWave;
     constexpr bool KPAIRS = (NU * NX) % 2 == 0 && RK % 2 == 0;
     constexpr int KU = KPAIRS ? NU * NX / 2 : NU * NX, JK = (TPW * KU + kWave - 1) / kWave;   // K pieces per slot / loads per lane
-    int kso[JK];                                               // image word of the lane's K piece, -1: none
+    int kso[JK];                                               // image word of the lane's K piece
     int64_t kgo[JK];                                           // its word in the K array at t = 0
 #pragma unroll
     for (int j = 0; j < JK; ++j) {
-        const int e = lane + kWave * j, sl = e / KU, pc = e - sl * KU;
+        // pieces of slots without a trajectory go where the shadowed trajectory's go (same words); lanes past the last piece
+        // repeat piece 0 of the first valid slot
+        const int e = lane + kWave * j, in = e < TPW * KU;
+        const int sl = in ? e / KU : ssh, pc = in ? e - (e / KU) * KU : 0;
         const int bk = blockIdx.x * TPW + sl;
-        const bool ok = sl < TPW && bk < p.B && (p.active == nullptr || p.active[bk] != 0);
-        kso[j] = ok ? sl * RW + RK + pc * (KPAIRS ? 2 : 1) : -1;
-        kgo[j] = ok ? (int64_t)bk * N * (NU * NX) + pc * (KPAIRS ? 2 : 1) : 0;
+        const bool ok = bk < p.B && (p.active == nullptr || p.active[bk] != 0);
+        kso[j] = sl * RW + RK + pc * (KPAIRS ? 2 : 1);
+        kgo[j] = (int64_t)(ok ? bk : bsh) * N * (NU * NX) + pc * (KPAIRS ? 2 : 1);
     }
     int fw[JP];                                                // image word of the lane's j-th record pair
 #pragma unroll
     for (int j = 0; j < JP; ++j) { const int pq = lane + kWave * j; fw[j] = 2 * (pq < NPAIR ? pq : NPAIR - 1); }
-    T *const recg = p.rec ? p.rec + (int64_t)blockIdx.x * N * (TPW * RW) : nullptr;   // the wavefront's records, step 0
+    T *const recg = REC ? p.rec + (int64_t)blockIdx.x * N * (TPW * RW) : nullptr;   // the wavefront's records, step 0
 
     // The image of a step is read back into fl / fk behind its sync (c) and leaves for HBM during the NEXT step, one store
     // between two blocks of that step's arithmetic: a wavefront waits while a store's data drains (the CU moves ~7-16 B per
@@ -287,14 +301,12 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     T fk1[JK];
     auto send = [&](int tq, int j) {                           // j-th of the JP + JK stores of step tq's image
         if (j < JP) {
-            if (recg) *reinterpret_cast<V2 *>(recg + (int64_t)tq * (TPW * RW) + fw[j < JP ? j : 0]) = fl[j < JP ? j : 0];
+            if constexpr (REC) *reinterpret_cast<V2 *>(recg + (int64_t)tq * (TPW * RW) + fw[j < JP ? j : 0]) = fl[j < JP ? j : 0];
         } else if (j < JP + JK) {
             const int jj = j - JP < JK ? (j - JP >= 0 ? j - JP : 0) : 0;
-            if (kso[jj] >= 0) {
-                T *dk = p.K + kgo[jj] + (int64_t)tq * (NU * NX);
-                if constexpr (KPAIRS) *reinterpret_cast<V2 *>(dk) = fk[jj];
-                else *dk = fk1[jj];
-            }
+            T *dk = p.K + kgo[jj] + (int64_t)tq * (NU * NX);
+            if constexpr (KPAIRS) *reinterpret_cast<V2 *>(dk) = fk[jj];
+            else *dk = fk1[jj];
         }
     };
     // the JP + JK stores take evenly spaced places among the 3 NX blocks of the step's three accumulation loops
@@ -321,39 +333,53 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         for (int j = 0; j < JA; ++j) rec[dA[j]] = g.ra[j];
 #pragma unroll
         for (int j = 0; j < JB; ++j) rec[dB[j]] = g.rb[j];
-        T c_now[W];
-#pragma unroll
-        for (int j = 0; j < W; ++j) c_now[j] = g.crow[j];
         T ff_c0v = T(0);
         if constexpr (FF) {
             rec[ff_ddst] = ff_dmask * (ff_hmask * g.hv - (g.zv - g.lv));
             ff_c0v = g.c0;
         }
         slot_sync();                                          // (a) ABs, Vs visible to the slot
-        fetch(t - D > 0 ? t - D : 0, g);                       // refill this ring entry (clamped, unconditional)
 
+        // Everything the step reads from the slot's V and [A B] goes into registers in ONE batch of LDS reads (a lone wavefront
+        // pays the full LDS latency at every wait: read-a-little / compute-a-little costs that latency ~50 times per step)
+        // V first; the rows of [A B] are requested one by one as the rows of V are used up, so they arrive while (1) computes
+        // and both are never in registers in full
+        T S[NX], colv[NX], Vr[NX][NX], Fr[NX][W];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) colv[k] = ABs[k * W + i];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) Vr[k][j] = Vs[k * NX + j];
+        }
+        T ff_v[NX], ff_dr[NX];
+        if constexpr (FF) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) { ff_v[k] = rec[VV_OFF + k]; ff_dr[k] = rec[ff_doff + k]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // (1) S = row i of [A B]'V
-        T S[NX], colv[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) S[j] = T(0);
         static_for<NX>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
-            const T col = ABs[k * W + i];
-            colv[k] = col;
 #pragma unroll
-            for (int j = 0; j < NX; ++j) S[j] += col * Vs[k * NX + j];
+            for (int j = 0; j < NX; ++j) S[j] += colv[k] * Vr[k][j];
+#pragma unroll
+            for (int c = 0; c < W; ++c) Fr[k][c] = ABs[k * W + c];
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, k>{});
         });
         // FF form: c_i, and the u-lanes' qu_r = cu_r + (B'v)_r from their column of B
-        T ff_ci = T(0), ff_v[NX];
+        T ff_ci = T(0);
         if constexpr (FF) {
-            ff_ci = ff_grad(ff_c0v);
+            T sacc = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) sacc += ff_row[j] * ff_dr[j];   // j >= lim: zero row entry times a neighbour word
+            ff_ci = ff_c0v + sacc;
             T acc = T(0);
 #pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                ff_v[k] = rec[VV_OFF + k];
-                acc += colv[k] * ff_v[k];
-            }
+            for (int k = 0; k < NX; ++k) acc += colv[k] * ff_v[k];
             rec[ff_cdst] = ff_ci;
             rec[ff_qdst] = ff_ci + acc;
         }
@@ -364,11 +390,13 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         static_for<NX>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
 #pragma unroll
-            for (int c = 0; c < W; ++c) M[c] += S[k] * ABs[k * W + c];
+            for (int c = 0; c < W; ++c) M[c] += S[k] * Fr[k][c];
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, NX + k>{});
         });
 #pragma unroll
-        for (int c = 0; c < W; ++c) M[c] = (c < NX) ? fma(c_now[c], zmask, M[c]) : c_now[c] + M[c];   // one rounding either way
+        for (int c = 0; c < W; ++c) M[c] = (c < NX) ? fma(g.crow[c], zmask, M[c]) : g.crow[c] + M[c];   // one rounding either way
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(t - D > 0 ? t - D : 0, g);                       // refill this ring entry (clamped, unconditional): ~1.5 steps ahead
         // (3) u-lanes publish their row of [Qux Quu] (x-lanes write the dump words)
 #pragma unroll
         for (int c = 0; c < W; ++c) rec[qdst + c] = M[c];
@@ -413,7 +441,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
             constexpr int k = decltype(KK)::value;
             T ph = colv[k];
 #pragma unroll
-            for (int r = 0; r < NU; ++r) ph += ABs[k * W + NX + r] * Kc[r];
+            for (int r = 0; r < NU; ++r) ph += Fr[k][NX + r] * Kc[r];
             phc[k] = ph;
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, 2 * NX + k>{});
         });
@@ -450,8 +478,8 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
             }
             T kv = kt[0];
 #pragma unroll
-            for (int r = 1; r < NU; ++r) kv = (a_row == r) ? kt[r] : kv;
-            if (valid && !xl) p.kff[o * NU + a_row] = kv;
+            for (int r = 1; r < NU; ++r) kv = (ff_ku == r) ? kt[r] : kv;
+            p.kff[o * NU + ff_ku] = kv;                        // every lane (x-lanes and shadows store copies)
             // v_i = (cx_i + (Phi'v)_i) + (K'cu)_i
             T acc = T(0), kcu = T(0);
 #pragma unroll
@@ -465,8 +493,8 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         for (int k = 0; k < NX; ++k) imq[r_b1 + k * r_s1] = phc[k];
 #pragma unroll
         for (int c = 0; c < NU; ++c) imq[r_b2 + c * r_s2] = tail[c];
-        if (valid) {
-            if (p.Qux) {
+        if constexpr (ARR) {
+            {
                 // cooperative store of [Qux Quu] rows and the factor (skipped when the caller only wants K and the packed
                 // records: every consumer of Qux / Quu / fac then reads the records instead)
 #pragma unroll
@@ -489,17 +517,26 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         const T *Ks = imq + s * RW + RK;
         // the finished image goes back into registers lane-linearly (unconditional reads, issued ahead of the V update whose
         // arithmetic covers their latency) and leaves for HBM behind it
+        if constexpr (REC) {
 #pragma unroll
-        for (int j = 0; j < JP; ++j) fl[j] = *reinterpret_cast<const V2 *>(imq + fw[j]);
+            for (int j = 0; j < JP; ++j) fl[j] = *reinterpret_cast<const V2 *>(imq + fw[j]);
+        }
 #pragma unroll
         for (int j = 0; j < JK; ++j) {
-            if constexpr (KPAIRS) fk[j] = *reinterpret_cast<const V2 *>(imq + (kso[j] >= 0 ? kso[j] : 0));
-            else fk1[j] = imq[kso[j] >= 0 ? kso[j] : 0];
+            if constexpr (KPAIRS) fk[j] = *reinterpret_cast<const V2 *>(imq + kso[j]);
+            else fk1[j] = imq[kso[j]];
         }
 
         // (5) V row i = Qxx + (K'Quu)K + Qux'K + K'Qux   (isls.py:300 / sls.py:153); u-lanes run the same instructions
         // on their zero column and write the dump words
         {
+            T Kr[NU][NX], Qxr[NU][NX];                         // K and Qux in one batch of reads
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) { Kr[r][j] = Ks[r * NX + j]; Qxr[r][j] = Qs[r * W + j]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             T Wr[NU];
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
@@ -513,10 +550,10 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                 T t1 = T(0), t2 = T(0), t3 = T(0);
 #pragma unroll
                 for (int r = 0; r < NU; ++r) {
-                    const T kj = Ks[r * NX + j];
+                    const T kj = Kr[r][j];
                     t1 += Wr[r] * kj;                          // (K'Quu) K
                     t2 += rhs[r] * kj;                         // Qux' K
-                    t3 += Kc[r] * Qs[r * W + j];               // K' Qux
+                    t3 += Kc[r] * Qxr[r][j];                   // K' Qux
                 }
                 const T vn = (MODE == ISLS_SOLVE_CHOL) ? ((M[j] + t1) + t2) + t3 : ((M[j] + t2) + t3) + t1;
                 rec[vdst + j] = vn;
@@ -571,29 +608,32 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     const bool with_ff = ff && a.rec && ff->rec == a.rec && ff->k && ff->B == a.B && ff->N == a.N && ff->n == a.n && ff->m == a.m &&
                          ff->solve_mode == a.solve_mode && ff->active == a.active && ff->c0x.p && ff->c0u.p &&
                          (!ff->Qr.p || ff->Qr.st == 0) && (!ff->Rr.p || ff->Rr.st == 0) && (!ff->Qr.p || (ff->zx && ff->lx)) &&
-                         (!ff->Rr.p || (ff->zu && ff->lu));
+                         (!ff->Rr.p || (ff->zu && ff->lu)) && !a.Qux;
     if (with_ff) {
         p.c0x = View<T>(ff->c0x); p.c0u = View<T>(ff->c0u); p.Qr = View<T>(ff->Qr); p.Rr = View<T>(ff->Rr);
         p.xhat = (const T *)ff->xhat; p.uhat = (const T *)ff->uhat;
         p.zx = (const T *)ff->zx; p.lx = (const T *)ff->lx; p.zu = (const T *)ff->zu; p.lu = (const T *)ff->lu;
         p.kff = (T *)ff->k;
     }
-#define LAUNCH_G(NX_, NU_, MODE_, FF_) \
-    hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_>), dim3(grid), dim3(64), 0, s, p)
+#define LAUNCH_G(NX_, NU_, MODE_, FF_, REC_, ARR_) \
+    hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_, REC_, ARR_>), dim3(grid), dim3(64), 0, s, p)
+#define LAUNCH_M(NX_, NU_, MODE_)                                                           \
+    {                                                                                       \
+        if (with_ff) LAUNCH_G(NX_, NU_, MODE_, true, true, false);                          \
+        else if (a.rec && !a.Qux) LAUNCH_G(NX_, NU_, MODE_, false, true, false);            \
+        else if (a.rec) LAUNCH_G(NX_, NU_, MODE_, false, true, true);                       \
+        else LAUNCH_G(NX_, NU_, MODE_, false, false, true);                                 \
+    }
 #define CALL(NX_, NU_)                                                                      \
     {                                                                                       \
         constexpr int TPW = kWave / (NX_ + NU_);                                            \
         const int grid = (a.B + TPW - 1) / TPW;                                             \
-        if (a.solve_mode == ISLS_SOLVE_CHOL) {                                              \
-            if (with_ff) LAUNCH_G(NX_, NU_, ISLS_SOLVE_CHOL, true);                         \
-            else LAUNCH_G(NX_, NU_, ISLS_SOLVE_CHOL, false);                                \
-        } else {                                                                            \
-            if (with_ff) LAUNCH_G(NX_, NU_, ISLS_SOLVE_INV, true);                          \
-            else LAUNCH_G(NX_, NU_, ISLS_SOLVE_INV, false);                                 \
-        }                                                                                   \
+        if (a.solve_mode == ISLS_SOLVE_CHOL) LAUNCH_M(NX_, NU_, ISLS_SOLVE_CHOL)            \
+        else LAUNCH_M(NX_, NU_, ISLS_SOLVE_INV)                                             \
     }
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
+#undef LAUNCH_M
 #undef LAUNCH_G
     if (did_ff) *did_ff = with_ff;
     return check_launch();
