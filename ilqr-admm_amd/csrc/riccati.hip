@@ -263,8 +263,10 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         }
     };
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < D; ++d) {
         fetch(N - 2 - d > 0 ? N - 2 - d : 0, ring[d]);          // unconditional (clamped): exact vmcnt bookkeeping
+        __builtin_amdgcn_sched_barrier(0);                      // issue order = consumption order
+    }
     bool pd_ok = true;
     // where a lane's W words of the packed record go: x-lane i -> column i of Phi (stride NX) then of K (stride NX);
     // u-lane r -> column r of B (stride NU) then row r of fac: 9 lanes x 9 words = the whole 81-word record at n=6, m=3

@@ -241,6 +241,255 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
     if (seg > 0 && valid && xl) p.vseg[((int64_t)b * p.nseg + seg) * NX + i] = vcur;   // v0 at the segment start
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form of the pass (time-invariant or absent Qr / Rr rows): ONE wave-internal hand-off and ONE batch of LDS reads
+// per step.  A wavefront with the SIMD to itself pays the whole LDS latency at every wait, so the step is organised around
+// its only true dependence, v:
+//   * cu is evaluated by every lane from the published d_u and c0u (m^2 multiply-adds) instead of being handed from the
+//     u-lanes to the x-lanes, so v' = (cx_i + (Phi'v)_i) + (K'cu)_i needs no second hand-off;
+//   * k_t = -Quu^-1 (cu + B'v) is off the recursion: the u-lanes publish qu_r with the step's v, and the NEXT step of the
+//     loop turns it into k_t with the cached factor it kept in registers;
+//   * every memory instruction is unconditional (lanes without a regularised block load c0 again, surplus lanes repeat the
+//     last lane, slots without a trajectory shadow the first valid one, every lane of a slot stores an entry of k_t), so
+//     the compiler's vmcnt bookkeeping stays exact and D steps of records really are in flight.
+// The sums are those of riccati_ffrec_kernel in the same order: results are bit-identical to it.
+template <typename T, int NX, int NU, int D, int OCC, int MODE>
+__global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
+{
+    constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
+    constexpr int PHI_OFF = 0, B_OFF = PHI_OFF + NX * NX, K_OFF = B_OFF + NX * NU, FAC_OFF = K_OFF + NU * NX, RW = rec_stride(NX, NU);
+    // slot: record | d[W] | c0u[NU] | v[NX] | qu[NU] | dump pair
+    constexpr int D_OFF = RW, C0U_OFF = D_OFF + W, V_OFF = C0U_OFF + NU, QU_OFF = V_OFF + NX, DUMP_OFF = (QU_OFF + NU + 1) & ~1;
+    constexpr int SLOT = DUMP_OFF + 2;                         // even: every slot's record starts on a 16-byte boundary
+    __shared__ __align__(16) T lds[(TPW + 1) * SLOT];
+    typedef T V2 __attribute__((ext_vector_type(2)));
+
+    const int lane = threadIdx.x;
+    const bool inslot = lane / G < TPW;
+    const int s = inslot ? lane / G : TPW - 1, i = inslot ? lane - (lane / G) * G : G - 1;   // surplus lanes repeat the last lane
+    const int b = blockIdx.x * TPW + s;
+    const bool valid = b < p.B && (p.active == nullptr || p.active[b] != 0);
+    const unsigned long long vmask = __ballot(valid);
+    if (vmask == 0ull) return;
+    const int bsh = __builtin_amdgcn_readlane(b, __builtin_ctzll(vmask));
+    const int bb = valid ? b : bsh;                            // slots without a trajectory shadow the first valid one
+    const int N = p.N;
+    const int seg = blockIdx.y;
+    const bool last = seg == p.nseg - 1;
+    const int t_lo = seg * p.seg_len, t_hi = last ? N - 2 : t_lo + p.seg_len - 1;
+    T *rec = lds + s * SLOT;
+    const bool xl = i < NX;
+    const int iu = xl ? 0 : i - NX;
+    const bool hasx = p.Qr.p != nullptr, hasu = p.Rr.p != nullptr;
+    const bool hasreg = xl ? hasx : hasu;
+
+    // records: blocked by wavefront, [block][t][slot][RW]; lane l fetches the 16-byte pairs l, l+64, ... of the step's run.
+    // A slot that shadows another trajectory still reads its own place in the run (whatever the gain pass left there) but
+    // restages the shadowed slot's record below, so it computes exactly what that slot computes.
+    constexpr int BW = TPW * RW, NP = BW / 2, JR = (NP + kWave - 1) / kWave;
+    const T *bR = p.rec + (int64_t)blockIdx.x * N * BW;
+    uint32_t oR[JR];
+    int dR[JR];
+#pragma unroll
+    for (int j = 0; j < JR; ++j) {
+        const int w = 2 * (lane + kWave * j);
+        oR[j] = (uint32_t)(w < BW ? w : BW - 2);
+        dR[j] = w < BW ? (w / RW) * SLOT + (w % RW) : TPW * SLOT + DUMP_OFF;
+    }
+    // where this lane READS its slot's record: its own slot, or the shadowed one
+    const int ssh = (bb - blockIdx.x * TPW);                   // slot of the trajectory the lane computes (== s when valid)
+    const T *rrec = lds + ssh * SLOT;
+    // vectors: own component of c0, xhat/uhat, z, lambda (lanes without a regularised block load c0 again and drop it)
+    const T *pc0 = xl ? p.c0x.at(bb, 0) + i : p.c0u.at(bb, 0) + iu;
+    const int64_t c0st = xl ? p.c0x.st : p.c0u.st;
+    const int dd = xl ? NX : NU;
+    const int64_t ovec = (int64_t)bb * N * dd + (xl ? i : iu);
+    const T *phat = xl ? p.xhat : p.uhat;
+    const bool hash = hasreg && phat != nullptr;
+    const T *ph = hash ? phat + ovec : pc0;
+    const T *pz = hasreg ? (xl ? p.zx : p.zu) + ovec : pc0, *pl = hasreg ? (xl ? p.lx : p.lu) + ovec : pc0;
+    const int64_t vst = hasreg ? dd : c0st, hst = hash ? dd : c0st;
+    const T dmask = hasreg ? T(1) : T(0), hmask = hash ? T(1) : T(0);
+    // 2 * rows of the ADMM weights: the lane's own row of Qr (x-lanes) and all of Rr (every lane evaluates cu)
+    T qrow[NX], rr2[NU][NU];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) qrow[j] = (xl && hasx) ? T(2) * p.Qr.at(bb, 0)[i * NX + j] : T(0);
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) rr2[r][c] = hasu ? T(2) * p.Rr.at(bb, 0)[r * NU + c] : T(0);
+    }
+    const T xmask = xl ? T(1) : T(0);
+
+    struct Stage {
+        V2 rr[JR];
+        T c0, hv, zv, lv;
+    };
+    auto fetch = [&](int tq, Stage &g) {
+        const int t = __builtin_amdgcn_readfirstlane(tq);
+        const T *r = bR + (int64_t)t * BW;
+#pragma unroll
+        for (int j = 0; j < JR; ++j) g.rr[j] = *reinterpret_cast<const V2 *>(r + oR[j]);
+        g.c0 = pc0[(int64_t)t * c0st];
+        g.hv = ph[(int64_t)t * hst];
+        g.zv = pz[(int64_t)t * vst];
+        g.lv = pl[(int64_t)t * vst];
+    };
+    const int d_dst = D_OFF + i;                               // own d component (x-lanes: d_x[i]; u-lanes: d_u[r] at D_OFF + NX + r)
+    const int c_dst = xl ? DUMP_OFF : C0U_OFF + iu;            // u-lanes publish c0u_r
+    const int o_dst = xl ? V_OFF + i : QU_OFF + iu;            // x-lanes publish v_i, u-lanes qu_r
+    const int cbase = xl ? PHI_OFF + i : B_OFF + iu, cstr = xl ? NX : NU;   // own column of [Phi | B]
+    const int ic = xl ? i : 0;
+    const int ku = xl ? i % NU : iu;                           // the entry of k this lane stores (x-lanes: copies)
+    T *const kbase = p.k + (int64_t)bb * N * NU + ku;
+
+    // ---- terminal step: v = cx[N-1] (last segment; the others start from v_in = 0), qu = 0 -> k[t_hi + 1] ... -------------
+    T vcur;
+    {
+        Stage term;
+        fetch(N - 1, term);
+        rec[d_dst] = dmask * (hmask * term.hv - (term.zv - term.lv));
+        slot_sync();
+        T sacc = T(0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) sacc += qrow[j] * rrec[D_OFF + j];
+        const T cterm = term.c0 + sacc;                        // u-lanes: unused
+        vcur = (last && xl) ? cterm : T(0);
+        rec[o_dst] = xl ? vcur : T(0);                         // v, and qu = 0: the first k the loop emits is k[N-1] = 0 (last segment)
+        slot_sync();
+    }
+    Stage ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        fetch(t_hi - d > t_lo ? t_hi - d : t_lo, ring[d]);
+        __builtin_amdgcn_sched_barrier(0);                     // issue order = consumption order: vmcnt is in order, and a prologue
+    }                                                          // the scheduler shuffled costs a vmcnt(0) at the top of every trip
+    T fac_h[NU][NU];                                           // cached factor of the step whose qu is pending
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) fac_h[r][c] = (r == c) ? T(1) : T(0);
+    }
+    // k of the step before: its row index.  The first iteration of a segment but the last has no pending step: it stores a
+    // throw-away value into its OWN step's entry, which the next iteration overwrites (same lane, same address, in order).
+    int tprev = last ? N - 1 : t_hi;
+
+    for (int tb = t_hi; tb >= t_lo; tb -= D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = tb - d;
+            const bool live = t >= t_lo;                       // uniform
+            Stage &g = ring[d];
+            // stage the records of the step and publish d_i (u-lanes: c0u_r as well)
+#pragma unroll
+            for (int j = 0; j < JR; ++j) *reinterpret_cast<V2 *>(lds + dR[j]) = g.rr[j];
+            rec[d_dst] = dmask * (hmask * g.hv - (g.zv - g.lv));
+            rec[c_dst] = g.c0;
+            const T c0_own = g.c0;
+            slot_sync();
+            fetch(t - D > t_lo ? t - D : t_lo, g);             // refill (clamped, unconditional)
+            // ---- one batch of reads ----
+            T dx[NX], du[NU], c0u[NU], col[NX], vv[NX], kcol[NU], facn[NU][NU], qup[NU];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) { dx[j] = rrec[D_OFF + j]; col[j] = rrec[cbase + j * cstr]; vv[j] = rrec[V_OFF + j]; }
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                du[r] = rrec[D_OFF + NX + r]; c0u[r] = rrec[C0U_OFF + r]; kcol[r] = rrec[K_OFF + r * NX + ic]; qup[r] = rrec[QU_OFF + r];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) facn[r][c] = rrec[FAC_OFF + r * NU + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // cu (every lane), c_i, the lane's column of [Phi | B] against v
+            T cu[NU];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                T sacc = T(0);
+#pragma unroll
+                for (int c = 0; c < NU; ++c) sacc += rr2[r][c] * du[c];
+                cu[r] = c0u[r] + sacc;
+            }
+            T sx = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) sx += qrow[j] * dx[j];
+            T ci = c0_own + sx;                                // x-lanes: cx_i
+#pragma unroll
+            for (int r = 0; r < NU; ++r) ci = (!xl && iu == r) ? cu[r] : ci;
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) acc += col[k] * vv[k];
+            const T qi = ci + acc;                             // x-lanes: cx_i + (Phi'v)_i; u-lanes: qu_r
+            T kcu = T(0);
+#pragma unroll
+            for (int r = 0; r < NU; ++r) kcu += kcol[r] * cu[r];
+            const T vnew = qi + kcu;
+            vcur = live ? vnew : vcur;
+            // k of the previous step from its cached factor and qu (this step's hand-off delivered qu)
+            T kt[NU];
+            if constexpr (MODE == ISLS_SOLVE_CHOL) {
+                T rd[NU], x[NU];
+#pragma unroll
+                for (int r = 0; r < NU; ++r) rd[r] = fac_h[r][r];
+                chol_solve<NU>(fac_h, rd, qup, x);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) kt[r] = T(0) - x[r];     // -x, and +0 for the k[N-1] = 0 the first iteration emits
+            } else {
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+                    T a2 = T(0);
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) a2 += fac_h[r][c] * qup[c];
+                    kt[r] = T(0) - a2;
+                }
+            }
+            T kv = kt[0];
+#pragma unroll
+            for (int r = 1; r < NU; ++r) kv = (ku == r) ? kt[r] : kv;
+            kbase[(int64_t)tprev * NU] = kv;
+            // publish v_i / qu_r (dead steps publish what is there already: vcur, and the pending qu again)
+            T outv = xl ? vcur : qi;
+#pragma unroll
+            for (int r = 0; r < NU; ++r) outv = (!live && !xl && iu == r) ? qup[r] : outv;
+            rec[o_dst] = outv;
+            if (live) {                                        // uniform: scalar bookkeeping only
+                tprev = t;
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) fac_h[r][c] = facn[r][c];
+                }
+            }
+        }
+    }
+    // ---- epilogue: k of the segment's first step from the last hand-off ---------------------------------------------------
+    slot_sync();
+    {
+        T qup[NU], kt[NU];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) qup[r] = rrec[QU_OFF + r];
+        if constexpr (MODE == ISLS_SOLVE_CHOL) {
+            T rd[NU], x[NU];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) rd[r] = fac_h[r][r];
+            chol_solve<NU>(fac_h, rd, qup, x);
+#pragma unroll
+            for (int r = 0; r < NU; ++r) kt[r] = -x[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                T a2 = T(0);
+#pragma unroll
+                for (int c = 0; c < NU; ++c) a2 += fac_h[r][c] * qup[c];
+                kt[r] = -a2;
+            }
+        }
+        T kv = kt[0];
+#pragma unroll
+        for (int r = 1; r < NU; ++r) kv = (ku == r) ? kt[r] : kv;
+        kbase[(int64_t)tprev * NU] = kv;
+    }
+    if (seg > 0 && valid && xl) p.vseg[((int64_t)b * p.nseg + seg) * NX + i] = vcur;   // v0 at the segment start
+}
+
 template <typename T>
 int launch_ff_record(const isls_ff_args &a, hipStream_t s)
 {
@@ -256,11 +505,26 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
     p.seg_len = segmented ? a.seg.seg_len : (a.N > 1 ? a.N - 1 : 1);
     p.vseg = segmented ? (T *)a.seg.v : nullptr;
     const bool rowc = (!a.Qr.p || a.Qr.st == 0) && (!a.Rr.p || a.Rr.st == 0);
+#ifndef ISLS_FF2_SEQ_DEPTH
+#define ISLS_FF2_SEQ_DEPTH 3
+#endif
+#ifndef ISLS_FF2_SEG_DEPTH
+#define ISLS_FF2_SEG_DEPTH 2
+#endif
+    static const bool v2_on = [] { const char *e = getenv("ISLS_FF_V2"); return !e || atoi(e) != 0; }();
+#define LAUNCH2(NX_, NU_, MODE_)                                                                                        \
+    {                                                                                                                   \
+        if (segmented) hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEG_DEPTH, 2, MODE_>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
+        else hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEQ_DEPTH, 1, MODE_>), dim3(grid), dim3(64), 0, s, p);                 \
+    }
 #define CALL(NX_, NU_)                                                                                                  \
     {                                                                                                                   \
         p.tpw = kWave / (NX_ + NU_);            /* the record layout is blocked by the gain pass's slots per wavefront */ \
         const int grid = (a.B + p.tpw - 1) / p.tpw;                                                                     \
-        if (segmented && rowc)                                                                                          \
+        if (rowc && v2_on) {                                                                                            \
+            if (a.solve_mode == ISLS_SOLVE_CHOL) LAUNCH2(NX_, NU_, ISLS_SOLVE_CHOL)                                     \
+            else LAUNCH2(NX_, NU_, ISLS_SOLVE_INV)                                                                      \
+        } else if (segmented && rowc)                                                                                   \
             hipLaunchKernelGGL((riccati_ffrec_kernel<T, NX_, NU_, ISLS_FFREC_SEG_DEPTH, ISLS_FFREC_SEG_OCC, ISLS_FFREC_GROUP, true>), dim3(grid, p.nseg), dim3(64), 0, s, p);  \
         else if (segmented)                                                                                             \
             hipLaunchKernelGGL((riccati_ffrec_kernel<T, NX_, NU_, ISLS_FFREC_SEG_DEPTH, ISLS_FFREC_SEG_OCC, ISLS_FFREC_GROUP, false>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
@@ -271,6 +535,7 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
     }
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
+#undef LAUNCH2
     return check_launch();
 }
 template int launch_ff_record<double>(const isls_ff_args &, hipStream_t);

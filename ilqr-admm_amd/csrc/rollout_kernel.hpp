@@ -277,10 +277,11 @@ template <typename T, int NX, int RPL>
 struct RoWOp {
     T K[RPL * NX], k[RPL], uh[RPL], xh[NX];
 };
-// has_xh / has_uh are wave-uniform (kernel arguments): a test on the per-lane pointer would put the loads behind exec-mask branches
+// Raw, unconditional loads (absent xhat / uhat: the caller passes a pointer into K and multiplies the words by zero where it
+// uses them): a branch in the fetch, even a wave-uniform one, makes the compiler wait for vmcnt(0) in the replay loop and
+// the ring of operands in flight is gone.
 template <typename T, int NX, int NU, int RPL>
-__device__ __forceinline__ void ro_wfetch(RoWOp<T, NX, RPL> &o, const T *wK, const T *wk, const T *wxh, const T *wuh, bool has_xh,
-                                          bool has_uh, int i, int last)
+__device__ __forceinline__ void ro_wfetch(RoWOp<T, NX, RPL> &o, const T *wK, const T *wk, const T *wxh, const T *wuh, int i, int last)
 {
     const int ii = i < last ? i : last;
     const T *qK = wK + (int64_t)ii * (NU * NX), *qk = wk + (int64_t)ii * NU;
@@ -288,25 +289,15 @@ __device__ __forceinline__ void ro_wfetch(RoWOp<T, NX, RPL> &o, const T *wK, con
     for (int e = 0; e < RPL * NX; ++e) o.K[e] = qK[e];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) o.k[r] = qk[r];
-    if (has_xh) {
-        const T *qx = wxh + (int64_t)ii * NX;
+    const T *qx = wxh + (int64_t)ii * NX;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) o.xh[j] = qx[j];
-    } else {
+    for (int j = 0; j < NX; ++j) o.xh[j] = qx[j];
+    const T *qu = wuh + (int64_t)ii * NU;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) o.xh[j] = T(0);
-    }
-    if (has_uh) {
-        const T *qu = wuh + (int64_t)ii * NU;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) o.uh[r] = qu[r];
-    } else {
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) o.uh[r] = T(0);
-    }
+    for (int r = 0; r < RPL; ++r) o.uh[r] = qu[r];
 }
 
-template <typename T, int NX, int NU, int MODEL, int RL, int WD>
+template <typename T, int NX, int NU, int MODEL, int RL, int WD, bool STAGE>
 __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, int c, int ind, bool valid, bool accept, bool stage_on,
                                           int N, int NSEG, int S, int64_t bN, T alpha_w, const T *pK, const T *pk, const T *pxh,
                                           const T *puh, const T *ck, T *stage, T *ubuf, T *x_out, T *u_out)
@@ -322,16 +313,19 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
 #pragma unroll
     for (int j = 0; j < NX; ++j) xw[j] = ck[(ind * NSEG + sg) * NX + j];
     slot_sync();                                               // every checkpoint is read before the stage overwrites it
-    if (c < nl) {
+    // every lane runs the loop: lanes past the last segment repeat lane 0 (same loads, same LDS writes), so that no memory
+    // instruction of the loop is conditional
+    {
         const bool wl = valid;
         const T *wK = pK + (bN + t0) * NU * NX + r0 * NX, *wk = pk + (bN + t0) * NU + r0;
         const bool has_xh = pxh != nullptr, has_uh = puh != nullptr;      // uniform
-        const T *wxh = has_xh ? pxh + (bN + t0) * NX : pK, *wuh = has_uh ? puh + (bN + t0) * NU + r0 : pK;
+        const T xhm = has_xh ? T(1) : T(0), uhm = has_uh ? T(1) : T(0);
+        const T *wxh = has_xh ? pxh + (bN + t0) * NX : pK + bN * NU * NX, *wuh = has_uh ? puh + (bN + t0) * NU + r0 : pK + bN * NU * NX;
         const int last = N - 1 - t0;                           // iterations beyond it repeat step N-1 (loads only)
         WOp ring[WD];
 #pragma unroll
         for (int d = 0; d < WD; ++d) {
-            ro_wfetch<T, NX, NU, RPL>(ring[d], wK, wk, wxh, wuh, has_xh, has_uh, d, last);
+            ro_wfetch<T, NX, NU, RPL>(ring[d], wK, wk, wxh, wuh, d, last);
             __builtin_amdgcn_sched_barrier(0);
         }
         T *xo = x_out + (bN + t0) * NX, *uo = u_out + (bN + t0) * NU + r0;   // direct stores when the stage does not fit
@@ -343,14 +337,14 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
                 const int i = i0 + d, t = t0 + i;
                 const bool in = wl && i < S && t < t1;
                 const WOp o = ring[d];
-                ro_wfetch<T, NX, NU, RPL>(ring[d], wK, wk, wxh, wuh, has_xh, has_uh, i + WD, last);
+                ro_wfetch<T, NX, NU, RPL>(ring[d], wK, wk, wxh, wuh, i + WD, last);
                 T uown[RPL], u[NU];
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
                     T acc = T(0);
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) acc += (xw[j] - o.xh[j]) * o.K[r * NX + j];
-                    uown[r] = (acc + alpha_w * o.k[r]) + o.uh[r];
+                    for (int j = 0; j < NX; ++j) acc += fma(-xhm, o.xh[j], xw[j]) * o.K[r * NX + j];   // x - xhat, one rounding
+                    uown[r] = fma(uhm, o.uh[r], acc + alpha_w * o.k[r]);                                // ... + uhat
                 }
                 if constexpr (RL > 1) {                        // the segment's lanes swap their rows of u
 #pragma unroll
@@ -363,7 +357,7 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
 #pragma unroll
                     for (int r = 0; r < NU; ++r) u[r] = uown[r];
                 }
-                if (stage_on) {
+                if constexpr (STAGE) {
                     const bool xown = in && (RL == 1 || r0 == 0);      // the first lane of a segment stores x_t, every lane its rows of u_t
                     T *sx = stage + (xown ? t * NX : sdump), *su = stage + (in ? N * NX + t * NU + r0 : sdump);
                     const int sstx = xown ? 1 : 0, sstu = in ? 1 : 0;
@@ -371,13 +365,13 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
                     for (int j = 0; j < NX; ++j) sx[j * sstx] = xw[j];
 #pragma unroll
                     for (int r = 0; r < RPL; ++r) su[r * sstu] = uown[r];
-                } else if (in) {                               // long horizons: straight to HBM
+                } else if (in && c < nl) {                     // long horizons: straight to HBM
                     if (RL == 1 || r0 == 0) {
 #pragma unroll
-                        for (int j = 0; j < NX; ++j) xo[i * NX + j] = accept ? xw[j] : o.xh[j];
+                        for (int j = 0; j < NX; ++j) xo[i * NX + j] = accept ? xw[j] : xhm * o.xh[j];
                     }
 #pragma unroll
-                    for (int r = 0; r < RPL; ++r) uo[i * NU + r] = accept ? uown[r] : o.uh[r];
+                    for (int r = 0; r < RPL; ++r) uo[i * NU + r] = accept ? uown[r] : uhm * o.uh[r];
                 }
                 T xn[NX];
                 model.step(xw, u, xn);
@@ -709,12 +703,18 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
     {
         const T alpha_w = absolute ? T(1) : p.alphas[ind];
         const T *pxh = has_xh ? p.xhat : nullptr, *puh = has_uh ? p.uhat : nullptr;
-        if (p.seg_lanes > 1)
-            ro_replay<T, NX, NU, MODEL, NU, 4>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                               stage, c_aug, p.x_out, p.u_out);
+        if (p.seg_lanes > 1 && stage_on)
+            ro_replay<T, NX, NU, MODEL, NU, 4, true>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
+                                                     stage, c_aug, p.x_out, p.u_out);
+        else if (p.seg_lanes > 1)
+            ro_replay<T, NX, NU, MODEL, NU, 4, false>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
+                                                      stage, c_aug, p.x_out, p.u_out);
+        else if (stage_on)
+            ro_replay<T, NX, NU, MODEL, 1, 2, true>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
+                                                    stage, c_aug, p.x_out, p.u_out);
         else
-            ro_replay<T, NX, NU, MODEL, 1, 2>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                              stage, c_aug, p.x_out, p.u_out);
+            ro_replay<T, NX, NU, MODEL, 1, 2, false>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
+                                                     stage, c_aug, p.x_out, p.u_out);
     }
 #ifdef ISLS_DIAG
     const unsigned long long twloop_ = __builtin_readcyclecounter();

@@ -320,10 +320,12 @@ class Engine:
     def ff_seg(self, nseg_requested=None):
         """Segment descriptor over engine-owned buffers, or None for the sequential recursion."""
         if nseg_requested is None:
-            # measured on MI355X (DESIGN.md 5): below ~4k trajectories the pass is bound by the N dependent steps and
-            # more segments keep paying; above, it is bound by HBM throughput and 3 segments (<= 2 co-resident
-            # wavefronts per SIMD, no register spills) are the sweet spot
-            nseg_requested = int(os.environ.get("ISLS_FF_NSEG", "3" if self.B >= 4096 else "4"))
+            # measured on MI355X (DESIGN.md 5): from ~2k trajectories on the pass is bound by HBM throughput whatever its
+            # shape (82-87 us for 1, 2 or 3 segments at B=4096; 45 / 36+29 / 39+26 us pass+prepare at B=2048), so the
+            # sequential recursion wins: no operators to prepare per gain pass, no stitch launch per ADMM iteration.
+            # Smaller batches are bound by the N dependent steps and keep the time-parallel form (B=512: 42 us sequential,
+            # 30 us in four segments).
+            nseg_requested = int(os.environ.get("ISLS_FF_NSEG", "1" if self.B >= 2048 else "4"))
         nseg, seg_len = self.kern.ff_segments(self.N, nseg_requested)
         if nseg < 2:
             return None

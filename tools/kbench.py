@@ -48,10 +48,11 @@ def run(args):
     out = {}
     out["gain"] = timed(lambda: eng.gain(active=act, rec=rec), args.reps)
     out["ff"] = timed(lambda: eng.feedforward(active=act, seg=seg, rec=rec), args.reps)
-    out["prep"] = timed(lambda: eng.feedforward_prepare(seg, active=act, rec=rec), args.reps)
+    out["prep"] = timed(lambda: eng.feedforward_prepare(seg, active=act, rec=rec), args.reps) if seg is not None else 0.0
     out["rollout"] = timed(lambda: eng.rollout(L, active=act), args.reps)
     out["lin"] = timed(eng.linearize, args.reps)
     out["expand"] = timed(eng.expand, args.reps)
+    out["run_outer"] = timed(eng.run_outer, max(5, args.reps // 4))
     def outer():
         eng.linearize(); eng.expand(); eng.run_outer(); eng.accept_x_step(); eng.reduce()
     out["outer_it"] = timed(outer, max(5, args.reps // 4))
