@@ -117,6 +117,23 @@ DEFINE_ENTRY(riccati_ff_prepare, isls_ff_prepare_args, launch_ff_prepare, 4)
 DEFINE_ENTRY(rollout_ls, isls_rollout_args, launch_rollout, 2)
 DEFINE_ENTRY(admm_update, isls_admm_args, launch_admm, 3)
 
+ISLS_API int isls_riccati_gain_ff_f64(const isls_gain_args *g, const isls_ff_args *ff, void *stream)
+{
+    if (!g || !ff) return ISLS_ERR_ARG;
+    if (g->B == 0) return ISLS_OK;
+    bool done = false;
+    const int rc = launch_gain<double>(*g, (hipStream_t)stream, ff, &done, /*require_ff=*/true);
+    return rc != ISLS_OK ? rc : (done ? ISLS_OK : ISLS_ERR_UNSUPPORTED);
+}
+ISLS_API int isls_riccati_gain_ff_f32(const isls_gain_args *g, const isls_ff_args *ff, void *stream)
+{
+    if (!g || !ff) return ISLS_ERR_ARG;
+    if (g->B == 0) return ISLS_OK;
+    bool done = false;
+    const int rc = launch_gain<float>(*g, (hipStream_t)stream, ff, &done, /*require_ff=*/true);
+    return rc != ISLS_OK ? rc : (done ? ISLS_OK : ISLS_ERR_UNSUPPORTED);
+}
+
 ISLS_API int isls_expand_quadratic_f64(const isls_expand_args *a, void *stream)
 {
     if (a && a->B == 0) return ISLS_OK;

@@ -169,7 +169,9 @@ __host__ __device__ constexpr int rec_stride(int n, int m) { return (n * n + 2 *
 
 // Launch wrappers implemented one per .hip file; each returns ISLS_OK / ISLS_ERR_*.
 // ff != nullptr: the pass may also run the first feed-forward pass (same records, time-invariant Qr / Rr); *did_ff tells
-template <typename T> int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff = nullptr, bool *did_ff = nullptr);
+// require_ff: launch nothing unless the feed-forward pass can ride along (*did_ff stays false)
+template <typename T>
+int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff = nullptr, bool *did_ff = nullptr, bool require_ff = false);
 template <typename T> int launch_ff(const isls_ff_args &a, hipStream_t s);
 template <typename T> int launch_ff_record(const isls_ff_args &a, hipStream_t s);
 template <typename T> int launch_ff_prepare(const isls_ff_prepare_args &a, hipStream_t s);

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 }
 
 template <typename T>
-int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, bool *did_ff)
+int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, bool *did_ff, bool require_ff)
 {
     if (did_ff) *did_ff = false;
     if (a.B < 0 || a.N < 1 || !a.A.p || !a.Bm.p || !a.Cxx.p || !a.Cuu.p || !a.K) return ISLS_ERR_ARG;
@@ -611,6 +611,7 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
                          ff->solve_mode == a.solve_mode && ff->active == a.active && ff->c0x.p && ff->c0u.p &&
                          (!ff->Qr.p || ff->Qr.st == 0) && (!ff->Rr.p || ff->Rr.st == 0) && (!ff->Qr.p || (ff->zx && ff->lx)) &&
                          (!ff->Rr.p || (ff->zu && ff->lu)) && !a.Qux;
+    if (require_ff && !with_ff) return ISLS_OK;
     if (with_ff) {
         p.c0x = View<T>(ff->c0x); p.c0u = View<T>(ff->c0u); p.Qr = View<T>(ff->Qr); p.Rr = View<T>(ff->Rr);
         p.xhat = (const T *)ff->xhat; p.uhat = (const T *)ff->uhat;
@@ -640,8 +641,8 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     if (did_ff) *did_ff = with_ff;
     return check_launch();
 }
-template int launch_gain<double>(const isls_gain_args &, hipStream_t, const isls_ff_args *, bool *);
-template int launch_gain<float>(const isls_gain_args &, hipStream_t, const isls_ff_args *, bool *);
+template int launch_gain<double>(const isls_gain_args &, hipStream_t, const isls_ff_args *, bool *, bool);
+template int launch_gain<float>(const isls_gain_args &, hipStream_t, const isls_ff_args *, bool *, bool);
 
 
 }  // namespace isls

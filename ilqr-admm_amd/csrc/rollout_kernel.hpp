@@ -300,7 +300,7 @@ __device__ __forceinline__ void ro_wfetch(RoWOp<T, NX, RPL> &o, const T *wK, con
 template <typename T, int NX, int NU, int MODEL, int RL, int WD, bool STAGE>
 __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, int c, int ind, bool valid, bool accept, bool stage_on,
                                           int N, int NSEG, int S, int64_t bN, T alpha_w, const T *pK, const T *pk, const T *pxh,
-                                          const T *puh, const T *ck, T *stage, T *ubuf, T *x_out, T *u_out)
+                                          const T *puh, const T *ck, T *stage, T *ubuf, int gl, T *x_out, T *u_out)
 {
     constexpr int RPL = NU / RL;                               // control rows per lane
     static_assert(RPL * RL == NU, "lanes per segment must divide the control dimension");
@@ -329,15 +329,23 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
             __builtin_amdgcn_sched_barrier(0);
         }
         T *xo = x_out + (bN + t0) * NX, *uo = u_out + (bN + t0) * NU + r0;   // direct stores when the stage does not fit
-        const int sdump = N * (NX + NU);                       // stage word that absorbs the writes of steps outside a segment
+        // every lane has a dump word of its own (the slot's plain-cost words, free by now) for the writes it must not make:
+        // LDS writes of several lanes to ONE address are a bank conflict of that many ways, and these sit on the step's
+        // critical path
+        T *const dumpw = ubuf + gl + (c < gl ? c : 0);
+        const int sdump = (int)(dumpw - stage);
         T *ub = ubuf + sg * NU;
+        T *const ubw = c < nl ? ub + r0 : dumpw;               // lanes past the last segment repeat lane 0's arithmetic, not its writes
+        const int ubs = c < nl ? 1 : 0;
         for (int i0 = 0; i0 < S; i0 += WD) {
 #pragma unroll
             for (int d = 0; d < WD; ++d) {
                 const int i = i0 + d, t = t0 + i;
                 const bool in = wl && i < S && t < t1;
                 const WOp o = ring[d];
+#ifndef ISLS_RO_EXP_NOREFILL
                 ro_wfetch<T, NX, NU, RPL>(ring[d], wK, wk, wxh, wuh, i + WD, last);
+#endif
                 T uown[RPL], u[NU];
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
@@ -346,21 +354,30 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
                     for (int j = 0; j < NX; ++j) acc += fma(-xhm, o.xh[j], xw[j]) * o.K[r * NX + j];   // x - xhat, one rounding
                     uown[r] = fma(uhm, o.uh[r], acc + alpha_w * o.k[r]);                                // ... + uhat
                 }
+#ifdef ISLS_RO_EXP_NOXCHG
+                if constexpr (false) {
+#else
                 if constexpr (RL > 1) {                        // the segment's lanes swap their rows of u
+#endif
 #pragma unroll
-                    for (int r = 0; r < RPL; ++r) ub[r0 + r] = uown[r];
+                    for (int r = 0; r < RPL; ++r) ubw[r * ubs] = uown[r];
                     slot_sync();
 #pragma unroll
                     for (int r = 0; r < NU; ++r) u[r] = ub[r];
                     slot_sync();                               // read before the next iteration's rows land
                 } else {
 #pragma unroll
-                    for (int r = 0; r < NU; ++r) u[r] = uown[r];
+                    for (int r = 0; r < NU; ++r) u[r] = uown[r < RPL ? r : 0];
                 }
+#ifdef ISLS_RO_EXP_NOSTAGE
+                if constexpr (false) {
+#else
                 if constexpr (STAGE) {
-                    const bool xown = in && (RL == 1 || r0 == 0);      // the first lane of a segment stores x_t, every lane its rows of u_t
-                    T *sx = stage + (xown ? t * NX : sdump), *su = stage + (in ? N * NX + t * NU + r0 : sdump);
-                    const int sstx = xown ? 1 : 0, sstu = in ? 1 : 0;
+#endif
+                    const bool own = in && c < nl;
+                    const bool xown = own && (RL == 1 || r0 == 0);     // the first lane of a segment stores x_t, every lane its rows of u_t
+                    T *sx = stage + (xown ? t * NX : sdump), *su = stage + (own ? N * NX + t * NU + r0 : sdump);
+                    const int sstx = xown ? 1 : 0, sstu = own ? 1 : 0;
 #pragma unroll
                     for (int j = 0; j < NX; ++j) sx[j * sstx] = xw[j];
 #pragma unroll
@@ -700,22 +717,24 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
     // past the end of the last segment compute on clamped operands and write the dump word), so the loads of the next
     // iterations stay in flight behind the current one.  x_t, u_t go to the stage in LDS (or straight to HBM when the stage
     // does not fit the slot).
+#ifndef ISLS_RO_EXP_NOREPLAY
     {
         const T alpha_w = absolute ? T(1) : p.alphas[ind];
         const T *pxh = has_xh ? p.xhat : nullptr, *puh = has_uh ? p.uhat : nullptr;
         if (p.seg_lanes > 1 && stage_on)
             ro_replay<T, NX, NU, MODEL, NU, 4, true>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                                     stage, c_aug, p.x_out, p.u_out);
+                                                     stage, c_aug, GL, p.x_out, p.u_out);
         else if (p.seg_lanes > 1)
             ro_replay<T, NX, NU, MODEL, NU, 4, false>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                                      stage, c_aug, p.x_out, p.u_out);
+                                                      stage, c_aug, GL, p.x_out, p.u_out);
         else if (stage_on)
             ro_replay<T, NX, NU, MODEL, 1, 2, true>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                                    stage, c_aug, p.x_out, p.u_out);
+                                                    stage, c_aug, GL, p.x_out, p.u_out);
         else
             ro_replay<T, NX, NU, MODEL, 1, 2, false>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                                     stage, c_aug, p.x_out, p.u_out);
+                                                     stage, c_aug, GL, p.x_out, p.u_out);
     }
+#endif
 #ifdef ISLS_DIAG
     const unsigned long long twloop_ = __builtin_readcyclecounter();
 #endif

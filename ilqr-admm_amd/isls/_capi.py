@@ -17,7 +17,7 @@ try:  # torch is plumbing (device memory, streams); the binding itself works on 
 except Exception:  # pragma: no cover
     torch = None
 
-ABI_VERSION = 103            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
+ABI_VERSION = 104            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
@@ -174,7 +174,7 @@ class OuterArgs(C.Structure):
 
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
-            ("riccati_gain", "riccati_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
+            ("riccati_gain", "riccati_ff", "riccati_gain_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "reduce_convergence_table", "ilqr_admm_outer")] + \
            ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_error_string", "isls_timing_create",
             "isls_timing_destroy", "isls_timing_reset", "isls_timing_pause", "isls_timing_read_ms"]
@@ -463,6 +463,14 @@ class Kernels:
     def riccati_ff(self, *args, stream=None, **kw):
         a = self.ff_args(*args, **kw)
         return self._call("riccati_ff", _sfx(args[4]), a, stream)
+
+    def riccati_gain_ff(self, gain, ff, sfx, stream=None):
+        """Gain pass + first feed-forward pass in one launch (argument blocks from gain_args / ff_args)."""
+        fn = getattr(self.lib, f"isls_riccati_gain_ff_{sfx}")
+        fn.restype = C.c_int
+        rc = fn(C.byref(gain), C.byref(ff), C.c_void_p(stream or 0))
+        if rc != OK:
+            raise IslsError(f"isls_riccati_gain_ff_{sfx} -> {rc}: {self.lib.isls_error_string(rc).decode()}")
 
     @staticmethod
     def project_args(y_in, y_out, sets, rho=1.0, max_iter=200, threshold=1e-4, iters=None, active=None, cols=None,

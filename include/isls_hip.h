@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ISLS_VERSION 103   /* 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
+#define ISLS_VERSION 104   /* 104: isls_riccati_gain_ff_*; 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
 
 #define ISLS_OK 0
 #define ISLS_ERR_ARG (-1)
@@ -177,6 +177,14 @@ typedef struct isls_ff_args {
 
 int isls_riccati_ff_f64(const isls_ff_args *a, void *stream);
 int isls_riccati_ff_f32(const isls_ff_args *a, void *stream);
+
+/* Gain pass and the first feed-forward pass in one launch: iSLS.backward_pass_DP computes K and k in the same backward
+ * sweep (isls/isls.py:285-302); so does this entry, for the linear terms `ff` describes.  The outer driver uses it for the
+ * first of its J feed-forward passes.  Conditions (else ISLS_ERR_UNSUPPORTED): g->rec != NULL and ff->rec == g->rec,
+ * g->Quu == g->fac == g->Qux == NULL (records only), Qr / Rr absent or time-invariant (st == 0), same B, N, n, m,
+ * solve_mode and active as `g`.  ff->seg is ignored (the sweep is sequential); outputs: everything `g` writes, and ff->k. */
+int isls_riccati_gain_ff_f64(const isls_gain_args *g, const isls_ff_args *ff, void *stream);
+int isls_riccati_gain_ff_f32(const isls_gain_args *g, const isls_ff_args *ff, void *stream);
 
 /* Operators of the time-parallel feed-forward pass (see isls_ffseg): run after the gain pass whenever
  * A, B, K, Quu, fac or Qux changed.  Writes seg.G for t < (nseg-1)*seg_len and seg.Psi for 1 <= s <= nseg-2. */

@@ -494,3 +494,71 @@ def test_long_horizon_car(dual):
     d = OracleDriver(dk, problem_arrays(cfg, range(3)), rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
     d.run(2, 50, 3, 0.0)
     _report(dk)
+
+
+@pytest.mark.parametrize("mode,batch,with_x", [(capi.SOLVE_CHOL, 17, True), (capi.SOLVE_CHOL, 9, False), (capi.SOLVE_INV, 8, True)])
+def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x):
+    """isls_riccati_gain_ff_*: K and the first k of an outer iteration from ONE backward sweep (the way the reference's
+    backward_pass_DP computes them, isls/isls.py:285-302) -- against the oracle's gain pass followed by its sequential
+    feed-forward pass; time-varying A, B per trajectory, ragged last wavefront, inactive trajectories untouched."""
+    import torch
+    from dual import hip_kernels
+    from helpers import rho_to_weights
+    okern, hk = oracle, hip_kernels()
+    rng = np.random.default_rng(3)
+    cfg = P.config2(batch=batch, N=60, seed=2)
+    N, n, m, B = 60, 6, 3, batch
+    z = lambda *s_: np.zeros(s_)   # noqa: E731
+    # general layout: per-trajectory, time-varying perturbations of the double integrator
+    A = np.tile(cfg["A"][None, None], (B, N, 1, 1)) + 0.02 * rng.standard_normal((B, N, n, n))
+    Bm = np.tile(cfg["B"][None, None], (B, N, 1, 1)) + 0.02 * rng.standard_normal((B, N, n, m))
+    Rr, Qr = rho_to_weights(cfg["rho_u"], N, m)[:1], (rho_to_weights(0.3, N, n)[:1] if with_x else None)   # [1,d,d]: time-invariant
+    xhat, uhat = rng.standard_normal((B, N, n)), 0.3 * rng.standard_normal((B, N, m))
+    zx, zu = rng.standard_normal((B, N, n)), rng.standard_normal((B, N, m))
+    lx, lu = 0.1 * rng.standard_normal((B, N, n)), 0.1 * rng.standard_normal((B, N, m))
+    Cxx, Cuu, c0x, c0u = z(B, N, n, n), z(B, N, m, m), z(B, N, n), z(B, N, m)
+    okern.expand_quadratic(cfg["Qs"], cfg["zs"], cfg["seq"], cfg["u_std"], c0x, c0u, xhat=xhat, uhat=uhat, Cxx=Cxx, Cuu=Cuu,
+                           Qr=np.tile(Qr, (N, 1, 1)) if with_x else None, Rr=np.tile(Rr, (N, 1, 1)))
+    active = np.ones(B, dtype=np.int32)
+    active[[1, B - 2]] = 0
+    K0 = rng.standard_normal((B, N, m, n))                      # what inactive trajectories must keep
+    k0 = rng.standard_normal((B, N, m))
+    # oracle: gain, then the sequential feed-forward pass
+    K, Quu, fac, Qux, k = K0.copy(), z(B, N, m, m), z(B, N, m, m), z(B, N, m, n), k0.copy()
+    st = np.zeros(B, dtype=np.int32)
+    okern.riccati_gain(A, Bm, Cxx, Cuu, K, Quu, fac, Qux, solve_mode=mode, status=st, active=active)
+    kwx = dict(Qr=np.tile(Qr, (N, 1, 1)), zx=zx, lx=lx) if with_x else {}
+    okern.riccati_ff(A, Bm, c0x, c0u, K, Quu, fac, Qux, k, Rr=np.tile(Rr, (N, 1, 1)), xhat=xhat, uhat=uhat, zu=zu, lu=lu,
+                     solve_mode=mode, active=active, **kwx)
+    # HIP: one launch on the records (the argument blocks hold raw pointers: every device array stays referenced in `d`)
+    dev = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    d = {k_: dev(v) for k_, v in dict(A=A, Bm=Bm, Cxx=Cxx, Cuu=Cuu, c0x=c0x, c0u=c0u, K=K0, k=k0, Rr=Rr, xhat=xhat, uhat=uhat, zu=zu,
+                                      lu=lu, act=active, st=np.zeros(B, dtype=np.int32), Qr=Qr if with_x else None,
+                                      zx=zx if with_x else None, lx=lx if with_x else None).items()}
+    dK, dk_, dA, dB, dact, dst, dQr = d["K"], d["k"], d["A"], d["Bm"], d["act"], d["st"], d["Qr"]
+    rec = torch.full((capi.ff_record_elems(B, N, n, m),), float("nan"), dtype=torch.float64, device="cuda")
+    g = capi.Kernels.gain_args(dA, dB, d["Cxx"], d["Cuu"], dK, None, None, None, solve_mode=mode, status=dst, active=dact, rec=rec)
+    ff = capi.Kernels.ff_args(dA, dB, d["c0x"], d["c0u"], dK, None, None, None, dk_, Qr=dQr, Rr=d["Rr"], xhat=d["xhat"], uhat=d["uhat"],
+                              zx=d["zx"], lx=d["lx"], zu=d["zu"], lu=d["lu"], solve_mode=mode, active=dact, rec=rec)
+    hk.riccati_gain_ff(g, ff, "f64")
+    torch.cuda.synchronize()
+    for name, ref, got in (("K", K, dK), ("k", k, dk_)):
+        got = got.cpu().numpy()
+        assert np.isfinite(ref).all(), f"{name}: oracle not finite"
+        bad = np.argwhere(~np.isfinite(got))
+        assert bad.size == 0, f"{name}: HIP not finite at {bad[:6].tolist()} ({len(bad)} entries)"
+        err = np.max(np.abs(ref - got)) / max(1.0, np.max(np.abs(ref)))
+        assert err < 1e-10, f"{name}: rel err {err:.3e}"
+        assert np.array_equal(got[[1, B - 2]], (K0 if name == "K" else k0)[[1, B - 2]]), f"{name}: inactive trajectory touched"
+    assert np.array_equal(dst.cpu().numpy(), st)
+    # a second feed-forward pass on the same records (the ADMM state moved) agrees with the oracle's as well
+    zu2 = zu + 0.2 * rng.standard_normal(zu.shape)
+    k2 = k.copy()
+    okern.riccati_ff(A, Bm, c0x, c0u, K, Quu, fac, Qux, k2, Rr=np.tile(Rr, (N, 1, 1)), xhat=xhat, uhat=uhat, zu=zu2, lu=lu,
+                     solve_mode=mode, active=active, **kwx)
+    d["zu2"] = dev(zu2)
+    hk.riccati_ff(dA, dB, d["c0x"], d["c0u"], dK, None, None, None, dk_, Qr=dQr, Rr=d["Rr"], xhat=d["xhat"], uhat=d["uhat"],
+                  zx=d["zx"], lx=d["lx"], zu=d["zu2"], lu=d["lu"], solve_mode=mode, active=dact, rec=rec)
+    torch.cuda.synchronize()
+    err = np.max(np.abs(k2 - dk_.cpu().numpy())) / max(1.0, np.max(np.abs(k2)))
+    assert err < 1e-10, f"second pass k: rel err {err:.3e}"
