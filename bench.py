@@ -33,7 +33,7 @@ EVENT_PERIOD = 4               # kernel-family durations are sampled on every 4t
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 KIND_NAMES = ["riccati_gain_kernel", "riccati_ff_kernel", "rollout_kernel", "admm_update_kernel", "ff_prepare_kernel"]
 # kernels behind each timed family (isls_timing kind): the time-parallel feed-forward pass is two launches
-KIND_KERNELS = [["riccati_gain_kernel"], ["riccati_ff_kernel", "riccati_ffrec_kernel", "ff_stitch_kernel"], ["rollout_kernel"],
+KIND_KERNELS = [["riccati_gain_kernel"], ["riccati_ff_kernel", "riccati_ffrec_kernel", "riccati_ffrec2_kernel", "ff_stitch_kernel"], ["rollout_kernel"],
                 ["admm_update_kernel"], ["ff_prepare_kernel", "ff_prepare_rec_kernel"]]
 def _latest_pmc_file():
     """Newest committed PMC traffic table (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py)."""
@@ -60,18 +60,23 @@ def pmc_traffic(kind):
     return total if found else None
 
 
-def algorithmic_bytes(n, m, N, w, has_x, has_u, lti, hess_shared, records):
+def algorithmic_bytes(n, m, N, w, has_x, has_u, lti, hess_shared, records, gain_ff=False):
     """HBM bytes per trajectory per launch that each kernel family MUST move in the layout in use (each distinct array
     once; stride-0 shared tables cost nothing per trajectory):
       hess_shared : Cxx, Cuu are batch-shared [N,.,.] tables (Engine._shared_hessian) -> not counted;
       records     : the feed-forward passes read the packed step records [A+BK | B | K | fac] of the gain pass, so the
                     gain pass does not write Quu / fac / Qux and ff reads n^2+2nm+m^2 words per step instead of the six
                     arrays.  The records themselves are an internal layout: the gain pass is credited with A, B in and
-                    K out only (writing them is its own overhead), ff with what it reads."""
+                    K out only (writing them is its own overhead), ff with what it reads.
+      gain_ff     : the first feed-forward pass of an outer iteration rides on the gain pass (isls_riccati_gain_ff_*): that
+                    launch is credited with the pass's vectors as well (c0, the regularised blocks in, k out) -- not with
+                    the operators, which it never reads back."""
     ab = 0 if lti else n * n + n * m
     hess = 0 if hess_shared else n * n + m * m
     reg = (3 * n if has_x else 0) + (3 * m if has_u else 0)            # xhat/uhat, z, lambda of the regularised blocks
     gain = ab + hess + m * n + (0 if records else m * n + 2 * m * m)   # A,B,(Cxx,Cuu) in; K (,Qux,Quu,fac) out
+    if gain_ff:
+        gain += (n + m) + reg + m
     ops = (n * n + 2 * n * m + m * m) if records else (ab + 2 * m * n + 2 * m * m)
     ff = ops + (n + m) + reg + m                                       # operators, c0, reg in; k out
     ro = m * n + m + (n + m) + ((2 * n if has_x else 0) + (2 * m if has_u else 0)) + (n + m)   # K,k,nominal,z,l in; x,u out
@@ -250,7 +255,9 @@ def main():
         it_per_s = world * args.steps / dt
         w = 8
         records = eng.ff_record() is not None
-        abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti, hess_shared=hess_shared, records=records)
+        gain_ff = fam[1][1] < fam[2][1]                         # fewer ff launches than rollouts: the first pass rode on the gain pass
+        abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti, hess_shared=hess_shared, records=records,
+                                   gain_ff=gain_ff)
         nseg_ff = max(1, int(eng._outer_args.ff.seg.nseg))
         abytes[4] = abytes[4] * (nseg_ff - 1) / nseg_ff          # the operators cover every segment but the last
         sampled = len(range(0, args.steps, EVENT_PERIOD))
@@ -280,7 +287,8 @@ def main():
                        "cost_hessians": ("batch-shared [N,n,n] / [N,m,m] tables written once (via-point cost with a shared Q and rho; "
                                          "SURVEY 8d: Cxx,Cuu terms dropped)" if hess_shared else "per trajectory [B,N,n,n]"),
                        "early_exit": False, "lti_stride0_layout_iterations_per_s": lti_it_per_s,
-                       "ff_time_parallel_segments": max(1, int(eng._outer_args.ff.seg.nseg)), "trajectory_iterations_per_s": it_per_s * B,
+                       "ff_time_parallel_segments": max(1, int(eng._outer_args.ff.seg.nseg)),
+                       "first_ff_pass_inside_gain_pass": bool(gain_ff), "trajectory_iterations_per_s": it_per_s * B,
                        "admm_iterations_per_s": it_per_s * J},
             "roofline": {"bound": "hbm", "kernel": KIND_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -214,12 +214,29 @@ inline int check_launch()
     return hipGetLastError() == hipSuccess ? ISLS_OK : ISLS_ERR_LAUNCH;
 }
 
-// supported (n, m) pairs: the reference notebooks' systems
-#define ISLS_DISPATCH_DIMS(n, m, CALL)              \
-    if ((n) == 6 && (m) == 3) { CALL(6, 3); }       \
-    else if ((n) == 2 && (m) == 1) { CALL(2, 1); }  \
-    else if ((n) == 4 && (m) == 2) { CALL(4, 2); }  \
-    else if ((n) == 9 && (m) == 3) { CALL(9, 3); }  \
-    else return ISLS_ERR_UNSUPPORTED;
+// Supported (n, m) pairs: the reference notebooks' systems and every get_double_integrator_AB(nb_dim <= 3,
+// nb_deriv <= 3) system (isls/utils.py:266-276: n = nb_dim * nb_deriv, m = nb_dim).  The kernels are templates over the
+// dimensions (rows live in registers); a further pair is one line here, one in rollout.hip and one in the Makefile.
+#define ISLS_FOR_EACH_DIMS(X) X(6, 3) X(2, 1) X(4, 2) X(9, 3) X(3, 1) X(6, 2) X(2, 2) X(3, 3)
+#define ISLS_DISPATCH_DIMS(n, m, CALL)                  \
+    {                                                   \
+        const int n_ = (n), m_ = (m);                   \
+        if (n_ == 6 && m_ == 3) { CALL(6, 3); }         \
+        else if (n_ == 2 && m_ == 1) { CALL(2, 1); }    \
+        else if (n_ == 4 && m_ == 2) { CALL(4, 2); }    \
+        else if (n_ == 9 && m_ == 3) { CALL(9, 3); }    \
+        else if (n_ == 3 && m_ == 1) { CALL(3, 1); }    \
+        else if (n_ == 6 && m_ == 2) { CALL(6, 2); }    \
+        else if (n_ == 2 && m_ == 2) { CALL(2, 2); }    \
+        else if (n_ == 3 && m_ == 3) { CALL(3, 3); }    \
+        else return ISLS_ERR_UNSUPPORTED;               \
+    }
+inline bool dims_supported(int n, int m)
+{
+#define ISLS_DIMS_TEST_(NX_, NU_) if (n == NX_ && m == NU_) return true;
+    ISLS_FOR_EACH_DIMS(ISLS_DIMS_TEST_)
+#undef ISLS_DIMS_TEST_
+    return false;
+}
 
 }  // namespace isls

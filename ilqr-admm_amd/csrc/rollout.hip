@@ -14,6 +14,10 @@ ISLS_ROLLOUT_FAMILY_DECL(6, 3, ISLS_MODEL_LTI)
 ISLS_ROLLOUT_FAMILY_DECL(6, 3, ISLS_MODEL_DI)
 ISLS_ROLLOUT_FAMILY_DECL(2, 1, ISLS_MODEL_LTI)
 ISLS_ROLLOUT_FAMILY_DECL(2, 1, ISLS_MODEL_DI)
+ISLS_ROLLOUT_FAMILY_DECL(3, 1, ISLS_MODEL_LTI)
+ISLS_ROLLOUT_FAMILY_DECL(6, 2, ISLS_MODEL_LTI)
+ISLS_ROLLOUT_FAMILY_DECL(2, 2, ISLS_MODEL_LTI)
+ISLS_ROLLOUT_FAMILY_DECL(3, 3, ISLS_MODEL_LTI)
 
 template <typename T>
 int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_args *fused, bool *did_fuse)
@@ -71,6 +75,10 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_ar
     FAMILY(6, 3, ISLS_MODEL_DI)
     FAMILY(2, 1, ISLS_MODEL_LTI)
     FAMILY(2, 1, ISLS_MODEL_DI)
+    FAMILY(3, 1, ISLS_MODEL_LTI)
+    FAMILY(6, 2, ISLS_MODEL_LTI)
+    FAMILY(2, 2, ISLS_MODEL_LTI)
+    FAMILY(3, 3, ISLS_MODEL_LTI)
 #undef FAMILY
     if (did_fuse) *did_fuse = rc == ISLS_OK && p.fa_on != 0;   // the family launcher drops the fused update when the stage does not fit
     return rc;
@@ -144,6 +152,10 @@ int launch_dense_closed_loop(const isls_dense_loop_args &a, hipStream_t s)
     else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_DI) LAUNCH(4, 2, ISLS_MODEL_DI);
     else if (a.n == 2 && a.m == 1 && a.model == ISLS_MODEL_DI) LAUNCH(2, 1, ISLS_MODEL_DI);
     else if (a.n == 4 && a.m == 2 && a.model == ISLS_MODEL_TASSA) LAUNCH(4, 2, ISLS_MODEL_TASSA);
+    else if (a.n == 3 && a.m == 1 && a.model == ISLS_MODEL_LTI) LAUNCH(3, 1, ISLS_MODEL_LTI);
+    else if (a.n == 6 && a.m == 2 && a.model == ISLS_MODEL_LTI) LAUNCH(6, 2, ISLS_MODEL_LTI);
+    else if (a.n == 2 && a.m == 2 && a.model == ISLS_MODEL_LTI) LAUNCH(2, 2, ISLS_MODEL_LTI);
+    else if (a.n == 3 && a.m == 3 && a.model == ISLS_MODEL_LTI) LAUNCH(3, 3, ISLS_MODEL_LTI);
     else return ISLS_ERR_UNSUPPORTED;
 #undef LAUNCH
     return check_launch();

@@ -176,7 +176,7 @@ class OuterArgs(C.Structure):
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             ("riccati_gain", "riccati_ff", "riccati_gain_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "reduce_convergence_table", "ilqr_admm_outer")] + \
-           ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_error_string", "isls_timing_create",
+           ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_dims_supported", "isls_error_string", "isls_timing_create",
             "isls_timing_destroy", "isls_timing_reset", "isls_timing_pause", "isls_timing_read_ms"]
 
 
@@ -209,6 +209,23 @@ def load_hip_library(path=None):
     lib.isls_timing_read_ms.restype = C.c_double
     lib.isls_timing_read_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     return lib
+
+
+_DIMS_LIB = None
+
+
+def dims_supported(n, m):
+    """True when the HIP library carries kernels for state dimension n and control dimension m (isls_dims_supported)."""
+    global _DIMS_LIB
+    if _DIMS_LIB is None:
+        _DIMS_LIB = load_hip_library()
+        _DIMS_LIB.isls_dims_supported.restype = C.c_int32
+    return bool(_DIMS_LIB.isls_dims_supported(C.c_int32(int(n)), C.c_int32(int(m))))
+
+
+def supported_dims(n_max=16, m_max=8):
+    """The (x_dim, u_dim) pairs the loaded library was built for."""
+    return [(n, m) for n in range(1, n_max + 1) for m in range(1, m_max + 1) if dims_supported(n, m)]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -72,6 +72,11 @@ class Engine:
                                  "there is no CPU fallback")
         self.kern = kernels()
         self.B, self.N, self.n, self.m = int(batch), int(N), int(x_dim), int(u_dim)
+        if not capi.dims_supported(self.n, self.m):
+            # the kernels are templates over (x_dim, u_dim): fail here, not at the first kernel call
+            raise capi.IslsError(f"libisls_hip.so has no kernels for x_dim={self.n}, u_dim={self.m}; built pairs: "
+                                 f"{capi.supported_dims()} (one line per pair in csrc/isls_common.hpp, csrc/rollout.hip and "
+                                 f"csrc/Makefile adds another)")
         self.dtype, self.device = dtype, torch.device(device)
         self.sfx = "f64" if dtype == torch.float64 else "f32"
         B, N, n, m = self.B, self.N, self.n, self.m

@@ -578,6 +578,9 @@ int isls_ilqr_admm_outer_f64(const isls_outer_args *a, void *stream);
 int isls_ilqr_admm_outer_f32(const isls_outer_args *a, void *stream);
 
 int isls_version(void);
+/* 1 when the kernels are instantiated for state dimension n and control dimension m (the pairs are compile-time template
+ * arguments: csrc/isls_common.hpp ISLS_FOR_EACH_DIMS), else 0: every entry point returns ISLS_ERR_UNSUPPORTED for other pairs. */
+int32_t isls_dims_supported(int32_t n, int32_t m);
 const char *isls_error_string(int code);
 /* Per-kernel-family durations for bench.py: HIP events recorded on the launch stream around the launches that
  * isls_ilqr_admm_outer_* enqueues, kept in a CALLER-OWNED context (the library itself has no state): create one, put it

@@ -562,3 +562,30 @@ def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x):
     torch.cuda.synchronize()
     err = np.max(np.abs(k2 - dk_.cpu().numpy())) / max(1.0, np.max(np.abs(k2)))
     assert err < 1e-10, f"second pass k: rel err {err:.3e}"
+
+
+@pytest.mark.parametrize("nb_dim,nb_deriv", [(1, 3), (2, 3), (2, 1), (3, 1)])
+def test_further_state_control_dimensions(dual, nb_dim, nb_deriv):
+    """(x_dim, u_dim) beyond the notebooks' four systems: every get_double_integrator_AB(nb_dim <= 3, nb_deriv <= 3) system
+    (isls/utils.py:266-276) as a dense LTI model -- (3,1), (6,2), (2,2), (3,3) -- whole DP-form iLQR-ADMM traces (gain,
+    feed-forward on the records and in the array form, rollout, update) against the oracle, state and control boxes."""
+    rng = np.random.default_rng(10 * nb_dim + nb_deriv)
+    n, m, N, batch = nb_dim * nb_deriv, nb_dim, 40, 19
+    assert capi.dims_supported(n, m)
+    A, Bm = P.double_integrator_AB(nb_dim, nb_deriv, 0.05)
+    zs = np.zeros((batch, 2, n))
+    zs[:, 1, :nb_dim] = rng.uniform(0.5, 1.5, (batch, nb_dim))
+    seq = np.zeros(N, dtype=np.int32)
+    seq[N - 1] = 1
+    x0 = np.zeros((batch, n))
+    x0[:, :nb_dim] = rng.uniform(-0.5, 0.5, (batch, nb_dim))
+    cfg = dict(name="di_extra", n=n, m=m, N=N, dt=0.05, A=A, B=Bm, zs=zs, Qs=np.stack([np.zeros((n, n)), 1e2 * np.eye(n)]), seq=seq,
+               u_std=1e-2, x0=x0, u0=np.zeros((batch, N, m)), u_lo=-2.0, u_hi=2.0, rho_u=1e-1, relax=1.0, model=P.MODEL_LTI)
+    pa = problem_arrays(cfg, range(batch))
+    pa["x_lo"], pa["x_hi"] = np.full((N, n), -1.6), np.full((N, n), 1.6)
+    for ff_record, ff_nseg in ((True, 1), (False, 1), (True, 3)):
+        dk = dual(ff_record=ff_record, ff_nseg=ff_nseg)
+        d = OracleDriver(dk, pa, rho_x=0.05, rho_u=cfg["rho_u"], project_x=True)
+        d.run(2, 12, 3, 0.0)
+        _report(dk)
+    assert not capi.dims_supported(5, 7)
