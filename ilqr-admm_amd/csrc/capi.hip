@@ -76,7 +76,7 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
         }
         {
             ScopedTimer tm(tmg, 2, s);
-            if ((rc = launch_rollout<T>(a.ro, s, fuse ? &a.admm : nullptr, &fused)) != ISLS_OK) return rc;
+            if ((rc = launch_rollout<T>(a.ro, s, fuse ? &a.admm : nullptr, &fused, j == a.J - 1 || a.log != nullptr)) != ISLS_OK) return rc;
         }
         if (!fused) {
             ScopedTimer tm(tmg, 3, s);

@@ -179,7 +179,9 @@ template <typename T> int launch_ff_stitch(const isls_ff_args &a, hipStream_t s)
 bool ff_seg_enabled(const isls_ffseg &sg);
 int ff_segments(int N, int nseg_req, int *seg_len);
 template <typename T>
-int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_args *fused = nullptr, bool *did_fuse = nullptr);
+// last = false (fused form only): further ADMM iterations of the same outer iteration follow, the x-step of a trajectory that
+// goes on need not be written out
+int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_args *fused = nullptr, bool *did_fuse = nullptr, bool last = true);
 bool rollout_can_fuse_admm(const isls_rollout_args &r, const isls_admm_args &a);
 template <typename T> int launch_admm(const isls_admm_args &a, hipStream_t s);
 template <typename T> int launch_project(const isls_project_args &a, hipStream_t s);

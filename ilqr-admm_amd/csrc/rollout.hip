@@ -20,7 +20,7 @@ ISLS_ROLLOUT_FAMILY_DECL(2, 2, ISLS_MODEL_LTI)
 ISLS_ROLLOUT_FAMILY_DECL(3, 3, ISLS_MODEL_LTI)
 
 template <typename T>
-int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_args *fused, bool *did_fuse)
+int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_args *fused, bool *did_fuse, bool last)
 {
     if (did_fuse) *did_fuse = false;
     if (a.B < 0 || a.N < 1 || a.L < 1 || a.L > 64) return ISLS_ERR_ARG;
@@ -50,6 +50,7 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_ar
         return ISLS_ERR_UNSUPPORTED;
     p.nseg = 1; p.seg_len = a.N; p.stage_on = 0;             // set by the family launcher
     p.fa_on = 0;
+    p.fa_last = last ? 1 : 0;
     p.fa_zx = p.fa_lx = p.fa_zu = p.fa_lu = p.fa_res = p.fa_res_prev = nullptr;
     p.fa_active = p.fa_iters = nullptr;
     p.fa_proj_x = p.fa_proj_u = 0;
@@ -83,8 +84,8 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_ar
     if (did_fuse) *did_fuse = rc == ISLS_OK && p.fa_on != 0;   // the family launcher drops the fused update when the stage does not fit
     return rc;
 }
-template int launch_rollout<double>(const isls_rollout_args &, hipStream_t, const isls_admm_args *, bool *);
-template int launch_rollout<float>(const isls_rollout_args &, hipStream_t, const isls_admm_args *, bool *);
+template int launch_rollout<double>(const isls_rollout_args &, hipStream_t, const isls_admm_args *, bool *, bool);
+template int launch_rollout<float>(const isls_rollout_args &, hipStream_t, const isls_admm_args *, bool *, bool);
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Monte-Carlo closed loop of a dense causal controller about a nominal (iSLSBase.get_trajectory_sls,

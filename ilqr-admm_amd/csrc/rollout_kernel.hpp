@@ -53,6 +53,8 @@ struct RoP {
     // driver: the winner's x_t, u_t are in LDS, so the update costs two reads and two writes per element and saves a
     // launch and a second pass over x, u
     int fa_on, fa_proj_x, fa_proj_u;
+    int fa_last;                   // fused form: 0 = more ADMM iterations follow in this outer iteration, so x_out / u_out are
+                                   // needed only for the trajectories that stop now (nothing else reads them in between)
     T fa_relax, fa_tol_abs, fa_tol_rel;
     T *fa_zx, *fa_lx, *fa_zu, *fa_lu, *fa_res, *fa_res_prev;
     View<T> fa_xlo, fa_xhi, fa_ulo, fa_uhi;
@@ -738,17 +740,25 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
 #ifdef ISLS_DIAG
     const unsigned long long twloop_ = __builtin_readcyclecounter();
 #endif
-    // the winner's trajectory (or the kept nominal when the acceptance test failed: isls.py:365-369) leaves in one coalesced sweep
+    // the winner's trajectory (or the kept nominal when the acceptance test failed: isls.py:365-369) leaves in one coalesced
+    // sweep -- behind the fused ADMM update when that may tell that nobody will read it (fa_last == 0 and the trajectory goes on)
     slot_sync();
-    if (stage_on && valid && c < GL) {
-        T *xo = p.x_out + bN * NX, *uo = p.u_out + bN * NU;
-        if (accept) {
-            for (int e = c; e < N * NX; e += GL) xo[e] = stage[e];
-            for (int e = c; e < N * NU; e += GL) uo[e] = stage[N * NX + e];
-        } else {
-            for (int e = c; e < N * NX; e += GL) xo[e] = p.xhat[bN * NX + e];
-            for (int e = c; e < N * NU; e += GL) uo[e] = p.uhat[bN * NU + e];
-        }
+    bool write_out = stage_on && valid && c < GL;
+    bool fa_stop = false;
+#define ISLS_RO_WRITE_OUT()                                                                  \
+    if (write_out) {                                                                         \
+        T *xo = p.x_out + bN * NX, *uo = p.u_out + bN * NU;                                  \
+        if (accept) {                                                                        \
+            for (int e = c; e < N * NX; e += GL) xo[e] = stage[e];                           \
+            for (int e = c; e < N * NU; e += GL) uo[e] = stage[N * NX + e];                  \
+        } else {                                                                             \
+            for (int e = c; e < N * NX; e += GL) xo[e] = p.xhat[bN * NX + e];                \
+            for (int e = c; e < N * NU; e += GL) uo[e] = p.uhat[bN * NU + e];                \
+        }                                                                                    \
+    }
+    if (!p.fa_on || p.fa_last) {                               // uniform
+        ISLS_RO_WRITE_OUT()
+        write_out = false;
     }
 #ifdef ISLS_DIAG
     const unsigned long long twinner_ = __builtin_readcyclecounter();
@@ -821,24 +831,32 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
             prim += sqrt(sp);
             dual += sqrt(sd);
         });
+        {
+            // every lane of the slot evaluates the stop rule (same sums): the lanes need it to decide about the write-out
+            const T *prevr = p.fa_res_prev ? p.fa_res_prev + (int64_t)bb * 2 : nullptr;
+            if (p.fa_active && prevr) {
+                const T p0 = prevr[0], p1 = prevr[1];
+                if (prim < p.fa_tol_abs && dual < p.fa_tol_abs) fa_stop = true;
+                else {
+                    const T pc = fabs(p0 - prim) / (p0 + T(1e-30));
+                    const T dc = fabs(p1 - dual) / (p1 + T(1e-30));
+                    fa_stop = pc < p.fa_tol_rel && dc < p.fa_tol_rel;
+                }
+            }
+            slot_sync();                                       // res_prev is read by every lane before lane 0 overwrites it
+        }
         if (valid && c == 0) {
             T *res = p.fa_res + (int64_t)b * 2;
             T *prev = p.fa_res_prev ? p.fa_res_prev + (int64_t)b * 2 : nullptr;
-            if (p.fa_active && prev) {
-                bool stop = false;
-                if (prim < p.fa_tol_abs && dual < p.fa_tol_abs) stop = true;
-                else {
-                    const T pc = fabs(prev[0] - prim) / (prev[0] + T(1e-30));
-                    const T dc = fabs(prev[1] - dual) / (prev[1] + T(1e-30));
-                    stop = pc < p.fa_tol_rel && dc < p.fa_tol_rel;
-                }
-                if (stop) p.fa_active[b] = 0;
-            }
+            if (fa_stop) p.fa_active[b] = 0;
             res[0] = prim; res[1] = dual;
             if (prev) { prev[0] = prim; prev[1] = dual; }
             if (p.fa_iters) p.fa_iters[b] += 1;
         }
+        if (!fa_stop) write_out = false;                       // the trajectory goes on: its next x-step overwrites x_out / u_out
+        ISLS_RO_WRITE_OUT()
     }
+#undef ISLS_RO_WRITE_OUT
 #ifdef ISLS_DIAG
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
         printf("ro diag block %d: search %llu argmin %llu replay %llu writeout %llu sweep %llu cycles (N=%d nseg=%d S=%d JM=%d)\n",
