@@ -113,7 +113,9 @@ typedef struct isls_gain_args {
                             * for the feed-forward pass (isls_ff_args.rec).  Opaque to the caller: an allocation of
                             * isls_ff_record_elems(B,N,n,m) elements, laid out [ceil(B/T)][N][T][RW] with T = 64/(n+m)
                             * trajectories per wavefront, so that a wavefront streams one contiguous burst per step;
-                            * steps t = N-1 are not written                                                        */
+                            * steps t = N-1 are not written.  Scratch semantics: the places of trajectories that are
+                            * inactive (or past the batch in the last wavefront) are overwritten too, with a copy of
+                            * another trajectory's record -- a consumer must use the same `active` mask as this pass   */
 } isls_gain_args;
 
 /* elements of the packed-record buffer (see isls_gain_args.rec) */
