@@ -12,6 +12,8 @@ after ONE Riccati gain pass, and the z-step is isls_columns_admm around the row 
 `projections.ConvexSets`, the caller's numpy function otherwise).  Results equal the dense form up to rounding, including
 the last control (SURVEY 8a quirk i), which the dense form sets from its own cost term.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -142,6 +144,35 @@ class ColumnSolver:
                 self.du.permute(1, 2, 3, 0).reshape(e.B, e.N * e.m, self.C).cpu().numpy().astype(np.float64))
 
 
+class _LaggedAny:
+    """`bool(mask.any())` one iteration late: the flag of iteration j is copied to pinned host memory without blocking and
+    read while iteration j + 1 is already queued, so the host's launch work overlaps the kernels of the previous iteration
+    instead of waiting for them (a device sync per ADMM iteration made `isls_admm` host-bound: 1.19 ms per iteration for
+    0.65 ms of kernels).  The loop may run one iteration more than the reference's `break` -- with every problem inactive
+    the kernels of that iteration touch nothing."""
+
+    def __init__(self, device):
+        self.host = torch.ones(2, dtype=torch.int32).pin_memory()
+        self.ev = [torch.cuda.Event(), torch.cuda.Event()]
+        self.dev = torch.ones(2, dtype=torch.int32, device=device)
+        self.n = 0
+
+    def push(self, mask):
+        i = self.n & 1
+        self.dev[i] = mask.any()
+        self.host[i:i + 1].copy_(self.dev[i:i + 1], non_blocking=True)
+        self.ev[i].record()
+        self.n += 1
+
+    def previous_all_inactive(self):
+        """True when the mask pushed one call before the last one was all zero."""
+        if self.n < 2:
+            return False
+        i = (self.n - 2) & 1
+        self.ev[i].synchronize()
+        return int(self.host[i]) == 0
+
+
 def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=False, max_admm_iter=20, k_max=20,
               max_line_search=20, rho_x=None, rho_u=None, alpha=1, threshold=1e-3, verbose=False, log=False):
     """Returns (du [N m], phi_u [N m, dim]) of the last ADMM x-step (with a leading batch axis when batch > 1).
@@ -165,15 +196,23 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     L = int(max_line_search)
     logbuf = torch.zeros(J, B, 2, dtype=e.dtype, device=e.device)
     e.outer_active.fill_(1)
-    hist = [[float(c)] for c in np.atleast_1d(np.asarray(self.cost, dtype=np.float64))]
+    Hlog = np.full((B, int(k_max) + 1), np.nan)                                # cost history per problem (column 0: initial cost)
+    Hlog[:, 0] = np.atleast_1d(np.asarray(self.cost, dtype=np.float64))
+    n_hist = np.ones(B, dtype=np.int64)
     mask3 = lambda a: a.to(torch.bool).view(B, 1, 1)                          # noqa: E731
+    device_only = not self._host_ls and all(blk is None or blk["desc"] is not None for blk in cs.blocks.values())
+    graph = dict(g=None, eager_done=False) if (device_only and cs.constrained and e.profile_events is None and
+                                               os.environ.get("ISLS_ADMM_GRAPH", "1") != "0") else None
     for k in range(k_max):
         self._linearize(get_AB)
         self._expand_regularised(get_Cs)                                        # built-in cost on the device, else the caller's get_Cs (isls.py:548-560)
         cs.prepare(e.outer_active)
         cs.restart(e.outer_active)                                              # lmb restarts, z is warm-started (isls.py:613-616)
-        for j in range(J):
-            act = e.admm_active
+        lag = _LaggedAny(e.device)
+        act = e.admm_active
+
+        def admm_iteration():
+            """x-step (C feed-forward passes + column rollout), line search on d_u, z-step: ~25 launches on fixed buffers"""
             cs.x_step()
             # line search on d_u: open-loop rollouts of u_nom + alpha d_u, plain cost, first arg-min (isls.py:593-606)
             if self._host_ls:                                                   # callable model / cost: the open-loop search on the host
@@ -188,11 +227,36 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
             step = torch.where(act.to(torch.bool), e.alphas[:L][e.best.long()], torch.ones_like(e.cost_new))
             du[0].mul_(step.view(B, 1, 1))                                      # du_opt[:, 0] = alpha* d_u
             dx[0].copy_(torch.where(on, e.xx - e.xhat, dx[0]))                  # dx_opt[:, 0] = x_noms[ind] - x_nom
+            if cs.constrained:
+                cs.z_step(alpha, threshold, 1e-3)                               # isls.py:626-665
+
+        for j in range(J):
+            if graph is not None and graph["g"] is not None:
+                graph["g"].replay()
+            elif graph is not None and graph["eager_done"]:
+                # second iteration of the call: record the launches of one ADMM iteration (same buffers every iteration) in a
+                # HIP graph and replay it from now on -- the Python / ctypes work per launch (~25 launches, ~1 ms) was what
+                # bounded this loop, not its 0.65 ms of kernels
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g):
+                        admm_iteration()
+                    graph["g"] = g
+                    g.replay()
+                except Exception:                                               # capture refused: stay on the eager path
+                    graph = None
+                    admm_iteration()
+            else:
+                admm_iteration()
+                if graph is not None:
+                    graph["eager_done"] = True
             if not cs.constrained:
                 e.admm_iters.add_(act)
                 break
-            cs.z_step(alpha, threshold, 1e-3, log_row=logbuf[j])                # isls.py:626-665
-            if not bool(act.any().item()):
+            logbuf[j].copy_(e.res)
+            lag.push(act)
+            if lag.previous_all_inactive():
+                logbuf[j].zero_()                                               # this iteration ran on no problem: no log row
                 break
         # new nominal: x_nom + d_x, u_nom + d_u of the last x-step (isls.py:684-687); the setter evaluates its cost
         oa = mask3(e.outer_active)
@@ -207,21 +271,27 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
         cost = e.cost.cpu().numpy().astype(np.float64)
         self.cost_log.append(self.cost)
         active = e.outer_active.cpu().numpy().astype(bool)
-        for b in np.nonzero(active)[0]:
-            prev = hist[b][-1]
-            hist[b].append(float(cost[b]))
-            if verbose:
+        # every problem still iterating has the same history length (k + 2 entries after this append): the two stop rules are
+        # evaluated for all of them at once -- a Python loop over a thousand problems cost more than the ADMM iterations
+        ia = np.nonzero(active)[0]
+        if verbose:
+            for b in ia:
                 print("Iteration number ", k, "iSLS cost: ", cost[b])
-            stop = abs(cost[b] - prev) < 1e-4                                   # isls.py:695-697
-            if not stop and len(hist[b]) >= 5:                                  # oscillation test, isls.py:699-701 (NaN on short logs)
-                stop = abs(np.mean(hist[b][-4:]) - np.mean(hist[b][-8:-4])) < 1e-3
-            active[b] = not stop
+        prev = Hlog[ia, k]
+        Hlog[ia, k + 1] = cost[ia]
+        stop = np.abs(cost[ia] - prev) < 1e-4                                   # isls.py:695-697
+        if k + 2 >= 5:                                                          # oscillation test, isls.py:699-701
+            h = Hlog[ia, :k + 2]
+            osc = np.abs(h[:, -4:].mean(1) - h[:, -8:-4].mean(1)) < 1e-3        # hist[-8:-4] is shorter on short logs, like the slice
+            stop = stop | osc
+        active[ia] = ~stop
+        n_hist[ia] += 1
         e.outer_active.copy_(torch.as_tensor(active.astype(np.int32), device=e.device))
         if not active.any():
             break
     self.admm_iters = e.admm_iters.cpu().numpy()
     self.admm_logs = logbuf.cpu().numpy()
-    self.outer_iters = np.array([len(h) - 1 for h in hist])
+    self.outer_iters = n_hist - 1
     self._dx_columns, xu = cs.columns()
     du_out, phi_out = xu[..., 0], xu[..., 1:]
     return (du_out[0], phi_out[0]) if B == 1 else (du_out, phi_out)
@@ -258,7 +328,7 @@ def admm_sls_columns(self, project_x, project_u, max_iter, rho_x, rho_u, alpha, 
             e.admm_iters.fill_(1)
             break
         cs.z_step(alpha, tol, 1e-2, log_row=logbuf[j])
-        if not bool(e.admm_active.any().item()):
+        if not bool(e.admm_active.any().item()):                                # one problem class, a few iterations: the plain test
             break
     _, xu = cs.columns()
     du = xu[..., 0]
