@@ -589,3 +589,52 @@ def test_further_state_control_dimensions(dual, nb_dim, nb_deriv):
         d.run(2, 12, 3, 0.0)
         _report(dk)
     assert not capi.dims_supported(5, 7)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5])
+def test_short_horizons_through_the_record_path(dual, N):
+    """Horizons of one to five steps through the gain pass with packed records, the record form of the feed-forward pass and the
+    outer driver (first feed-forward pass inside the gain pass): no step, one step, an odd and an even number of steps --
+    the loops of these kernels run in pairs of steps with a peeled first step."""
+    cfg = P.config2(batch=9, N=max(N, 2), seed=5)
+    if N == 1:                                                 # config2 needs two steps to build its nominal: cut it back to one
+        cfg = dict(cfg, N=1, seq=np.array([1], dtype=np.int32), u0=cfg["u0"][:, :1])
+    pa = problem_arrays(cfg, range(9))
+    dk = dual(ff_record=True)
+    d = OracleDriver(dk, pa, rho_u=cfg["rho_u"], relax=cfg["relax"])
+    d.run(2, 7, 3, 0.0)
+    _report(dk)
+    # the same through isls_ilqr_admm_outer (gain + first ff in one launch) on the device, against the oracle's driver
+    from dual import hip_kernels
+    from helpers import rel_err
+    import torch
+    oracle_k = dk.oracle
+    o = OracleDriver(oracle_k, problem_arrays(cfg, range(9)), rho_u=cfg["rho_u"], relax=cfg["relax"])
+    o.run_c(7, 3)
+    class Dev:                                                 # device twin of the driver's arrays
+        pass
+    h = OracleDriver(oracle_k, problem_arrays(cfg, range(9)), rho_u=cfg["rho_u"], relax=cfg["relax"])
+    hk = hip_kernels()
+    names = [k for k, v in vars(h).items() if isinstance(v, np.ndarray)]
+    for k in names:
+        setattr(h, k, torch.from_numpy(getattr(h, k)).cuda())
+    h.pa = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in h.pa.items()}
+    h.kern = hk
+    h.dtype = np.float64
+    rec = torch.zeros(capi.ff_record_elems(9, cfg["N"], 6, 3), dtype=torch.float64, device="cuda")
+    pa_h, K = h.pa, capi.Kernels
+    alphas = torch.from_numpy(ALPHAS_[:7].astype(np.float64)).cuda()
+    h.linearize_expand()
+    gain = K.gain_args(h.A, h.Bm, h.Cxx, h.Cuu, h.K, None, None, None, status=h.status, active=h.admm_active, rec=rec)
+    ff = K.ff_args(h.A, h.Bm, h.c0x, h.c0u, h.K, None, None, None, h.k, Rr=h.Rr[:1], xhat=h.xhat, uhat=h.uhat, zu=h.zu, lu=h.lu,
+                   active=h.admm_active, rec=rec)
+    ro = K.rollout_args(pa_h["model"], pa_h["model_par"], h.K, h.k, h.xhat, h.uhat, alphas, pa_h["Qtab"], pa_h["ztab"], pa_h["seq"],
+                        pa_h["u_std"], h.xx, h.xu, best=h.best, cost_new=h.cost_new, wr=h.wr[:1], zu=h.zu, lu=h.lu, cost_cur=h.cost,
+                        status=h.status, active=h.admm_active)
+    admm = K.admm_args(h.xx, h.xu, h.res, zu=h.zu, lu=h.lu, u_lo=pa_h["u_lo"], u_hi=pa_h["u_hi"], relax=h.relax, tol_abs=0.0,
+                       tol_rel=0.0, res_prev=h.res_prev, active=h.admm_active)
+    hk.outer(gain, ff, ro, admm, 3, "f64", outer_active=h.outer_active)
+    torch.cuda.synchronize()
+    for name in ("K", "k", "xx", "xu", "zu", "lu", "res"):
+        e = rel_err(getattr(h, name).cpu().numpy(), getattr(o, name))
+        assert e < 1e-10, f"N={N} {name}: {e:.2e}"
