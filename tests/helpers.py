@@ -244,3 +244,33 @@ def tassa_arrays(g, bsel, dtype=np.float64):
              xhat=np.ascontiguousarray(g["x_nom0"][bsel]).astype(dtype), uhat=np.ascontiguousarray(g["u0"][bsel]).astype(dtype),
              u_lo=np.tile(np.array([-0.5, -2.0], dtype=dtype), (N, 1)), u_hi=np.tile(np.array([0.5, 2.0], dtype=dtype), (N, 1)))
     return d
+
+
+def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.0):
+    """One outer DP-form iLQR-ADMM iteration through the library's own driver (`isls_ilqr_admm_outer_*`: gain pass with the
+    first feed-forward pass inside, J x [ff -> rollout with the fused ADMM update]) on the device, and the same through the
+    oracle's driver on the host; returns the worst relative error over K, k, the x-step, z, lambda and the residuals."""
+    import torch
+    o = OracleDriver(oracle_kern, problem_arrays(cfg, bsel), rho_u=rho_u, relax=relax)
+    o.run_c(L, J)
+    h = OracleDriver(oracle_kern, problem_arrays(cfg, bsel), rho_u=rho_u, relax=relax)
+    for k in [k for k, v in vars(h).items() if isinstance(v, np.ndarray)]:
+        setattr(h, k, torch.from_numpy(getattr(h, k)).cuda())
+    h.pa = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in h.pa.items()}
+    h.kern = hip
+    B, N, n, m = h.B, h.N, h.n, h.m
+    rec = torch.zeros(capi.ff_record_elems(B, N, n, m), dtype=torch.float64, device="cuda")
+    pa, K = h.pa, capi.Kernels
+    alphas = torch.from_numpy(ALPHAS[:L].astype(np.float64)).cuda()
+    h.linearize_expand()
+    gain = K.gain_args(h.A, h.Bm, h.Cxx, h.Cuu, h.K, None, None, None, status=h.status, active=h.admm_active, rec=rec)
+    ff = K.ff_args(h.A, h.Bm, h.c0x, h.c0u, h.K, None, None, None, h.k, Rr=h.Rr[:1], xhat=h.xhat, uhat=h.uhat, zu=h.zu, lu=h.lu,
+                   active=h.admm_active, rec=rec)
+    ro = K.rollout_args(pa["model"], pa["model_par"], h.K, h.k, h.xhat, h.uhat, alphas, pa["Qtab"], pa["ztab"], pa["seq"],
+                        pa["u_std"], h.xx, h.xu, best=h.best, cost_new=h.cost_new, wr=h.wr[:1], zu=h.zu, lu=h.lu, cost_cur=h.cost,
+                        status=h.status, active=h.admm_active)
+    admm = K.admm_args(h.xx, h.xu, h.res, zu=h.zu, lu=h.lu, u_lo=pa["u_lo"], u_hi=pa["u_hi"], relax=h.relax, tol_abs=0.0,
+                       tol_rel=0.0, res_prev=h.res_prev, active=h.admm_active)
+    hip.outer(gain, ff, ro, admm, J, "f64", outer_active=h.outer_active)
+    torch.cuda.synchronize()
+    return max(rel_err(getattr(h, name).cpu().numpy(), getattr(o, name)) for name in ("K", "k", "xx", "xu", "zu", "lu", "res"))

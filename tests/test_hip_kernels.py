@@ -606,35 +606,6 @@ def test_short_horizons_through_the_record_path(dual, N):
     _report(dk)
     # the same through isls_ilqr_admm_outer (gain + first ff in one launch) on the device, against the oracle's driver
     from dual import hip_kernels
-    from helpers import rel_err
-    import torch
-    oracle_k = dk.oracle
-    o = OracleDriver(oracle_k, problem_arrays(cfg, range(9)), rho_u=cfg["rho_u"], relax=cfg["relax"])
-    o.run_c(7, 3)
-    class Dev:                                                 # device twin of the driver's arrays
-        pass
-    h = OracleDriver(oracle_k, problem_arrays(cfg, range(9)), rho_u=cfg["rho_u"], relax=cfg["relax"])
-    hk = hip_kernels()
-    names = [k for k, v in vars(h).items() if isinstance(v, np.ndarray)]
-    for k in names:
-        setattr(h, k, torch.from_numpy(getattr(h, k)).cuda())
-    h.pa = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in h.pa.items()}
-    h.kern = hk
-    h.dtype = np.float64
-    rec = torch.zeros(capi.ff_record_elems(9, cfg["N"], 6, 3), dtype=torch.float64, device="cuda")
-    pa_h, K = h.pa, capi.Kernels
-    alphas = torch.from_numpy(ALPHAS_[:7].astype(np.float64)).cuda()
-    h.linearize_expand()
-    gain = K.gain_args(h.A, h.Bm, h.Cxx, h.Cuu, h.K, None, None, None, status=h.status, active=h.admm_active, rec=rec)
-    ff = K.ff_args(h.A, h.Bm, h.c0x, h.c0u, h.K, None, None, None, h.k, Rr=h.Rr[:1], xhat=h.xhat, uhat=h.uhat, zu=h.zu, lu=h.lu,
-                   active=h.admm_active, rec=rec)
-    ro = K.rollout_args(pa_h["model"], pa_h["model_par"], h.K, h.k, h.xhat, h.uhat, alphas, pa_h["Qtab"], pa_h["ztab"], pa_h["seq"],
-                        pa_h["u_std"], h.xx, h.xu, best=h.best, cost_new=h.cost_new, wr=h.wr[:1], zu=h.zu, lu=h.lu, cost_cur=h.cost,
-                        status=h.status, active=h.admm_active)
-    admm = K.admm_args(h.xx, h.xu, h.res, zu=h.zu, lu=h.lu, u_lo=pa_h["u_lo"], u_hi=pa_h["u_hi"], relax=h.relax, tol_abs=0.0,
-                       tol_rel=0.0, res_prev=h.res_prev, active=h.admm_active)
-    hk.outer(gain, ff, ro, admm, 3, "f64", outer_active=h.outer_active)
-    torch.cuda.synchronize()
-    for name in ("K", "k", "xx", "xu", "zu", "lu", "res"):
-        e = rel_err(getattr(h, name).cpu().numpy(), getattr(o, name))
-        assert e < 1e-10, f"N={N} {name}: {e:.2e}"
+    from helpers import outer_iteration_on_device
+    err = outer_iteration_on_device(cfg, range(9), hip_kernels(), dk.oracle, 7, 3, cfg["rho_u"], cfg["relax"])
+    assert err < 1e-10, f"N={N}: {err:.2e}"
