@@ -18,6 +18,9 @@
 // younger ones are still travelling).
 #include "isls_common.hpp"
 
+// Ablation switch (wrong results by design; tools/ab_build.sh + tools/kbench.py): -DISLS_GAIN_EXP_NOFLUSH
+// drops the stores of the record image and of K -- the "gain pass without its stores" figure.
+
 namespace isls {
 
 constexpr int kGainDepth = 2;   // steps of A,B,C in flight per lane (a step takes ~2 us, far more than an HBM round trip; deeper rings

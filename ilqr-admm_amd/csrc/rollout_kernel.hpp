@@ -23,6 +23,9 @@
 //             trajectory is collected in LDS (over the dead records and checkpoints), leaves in one coalesced
 //             sweep, and the element-wise ADMM update of the outer driver rides on it.
 #pragma once
+// Ablation switches (wrong results by design; tools/ab_build.sh + tools/kbench.py): -DISLS_RO_EXP_NOREPLAY
+// (no winner replay), _NOREFILL (replay without its operand refills), _NOXCHG (no exchange of the control rows), _NOSTAGE
+// (no stage writes); -DISLS_DIAG prints cycle stamps of the phases.
 
 #include <type_traits>
 
