@@ -348,12 +348,14 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         // Everything the step reads from the slot's V and [A B] goes into registers in ONE batch of LDS reads (a lone wavefront
         // pays the full LDS latency at every wait: read-a-little / compute-a-little costs that latency ~50 times per step)
         // V first; the rows of [A B] are requested one by one as the rows of V are used up, so they arrive while (1) computes
-        // and both are never in registers in full
+        // and both are never in registers in full.  Where V and [A B] together exceed ~200 registers (n = 9) only AHEAD rows
+        // are in flight at a time -- the whole batch would spill into scratch memory.
+        constexpr int AHEAD = (NX * NX + NX * W <= 100) ? NX : 2;
         T S[NX], colv[NX], Vr[NX][NX], Fr[NX][W];
 #pragma unroll
         for (int k = 0; k < NX; ++k) colv[k] = ABs[k * W + i];
 #pragma unroll
-        for (int k = 0; k < NX; ++k) {
+        for (int k = 0; k < AHEAD; ++k) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) Vr[k][j] = Vs[k * NX + j];
         }
@@ -370,8 +372,15 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
             constexpr int k = decltype(KK)::value;
 #pragma unroll
             for (int j = 0; j < NX; ++j) S[j] += colv[k] * Vr[k][j];
+            if constexpr (k + AHEAD < NX) {                    // the next row of V that is not in flight yet
 #pragma unroll
-            for (int c = 0; c < W; ++c) Fr[k][c] = ABs[k * W + c];
+                for (int j = 0; j < NX; ++j) Vr[k + AHEAD][j] = Vs[(k + AHEAD) * NX + j];
+            }
+            if constexpr (k - (NX - AHEAD) >= 0) {             // the first AHEAD rows of [A B] are in flight when (1) ends
+                constexpr int kf = k - (NX - AHEAD);
+#pragma unroll
+                for (int c = 0; c < W; ++c) Fr[kf][c] = ABs[kf * W + c];
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, k>{});
         });
@@ -396,6 +405,11 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
             constexpr int k = decltype(KK)::value;
 #pragma unroll
             for (int c = 0; c < W; ++c) M[c] += S[k] * Fr[k][c];
+            if constexpr (k + AHEAD < NX) {
+#pragma unroll
+                for (int c = 0; c < W; ++c) Fr[k + AHEAD][c] = ABs[(k + AHEAD) * W + c];
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, NX + k>{});
         });
 #pragma unroll
@@ -594,6 +608,10 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     if (valid && i == 0 && !pd_ok && p.status) atomicOr(&p.status[b], ISLS_ST_NOT_PD);
 }
 
+// dimensions for which the pass with the feed-forward recursion inside keeps its operands in registers (at n = 9 it spills
+// into scratch memory: the first feed-forward pass then stays a launch of its own)
+constexpr bool gain_ff_dims(int n, int m) { return n * n + n * (n + m) <= 100; }
+
 template <typename T>
 int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, bool *did_ff, bool require_ff)
 {
@@ -610,7 +628,7 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     p.status = a.status; p.active = a.active;
     p.xhat = p.uhat = p.zx = p.lx = p.zu = p.lu = nullptr; p.kff = nullptr;
     // the first feed-forward pass rides along when it would run on this pass's records with time-invariant Qr / Rr rows
-    const bool with_ff = ff && a.rec && ff->rec == a.rec && ff->k && ff->B == a.B && ff->N == a.N && ff->n == a.n && ff->m == a.m &&
+    const bool with_ff = ff && gain_ff_dims(a.n, a.m) && a.rec && ff->rec == a.rec && ff->k && ff->B == a.B && ff->N == a.N && ff->n == a.n && ff->m == a.m &&
                          ff->solve_mode == a.solve_mode && ff->active == a.active && ff->c0x.p && ff->c0u.p &&
                          (!ff->Qr.p || ff->Qr.st == 0) && (!ff->Rr.p || ff->Rr.st == 0) && (!ff->Qr.p || (ff->zx && ff->lx)) &&
                          (!ff->Rr.p || (ff->zu && ff->lu)) && !a.Qux;
@@ -625,8 +643,9 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_, REC_, ARR_>), dim3(grid), dim3(64), 0, s, p)
 #define LAUNCH_M(NX_, NU_, MODE_)                                                           \
     {                                                                                       \
-        if (with_ff) LAUNCH_G(NX_, NU_, MODE_, true, true, false);                          \
-        else if (a.rec && !a.Qux) LAUNCH_G(NX_, NU_, MODE_, false, true, false);            \
+        if (with_ff) {                                                                      \
+            if constexpr (gain_ff_dims(NX_, NU_)) LAUNCH_G(NX_, NU_, MODE_, true, true, false); \
+        } else if (a.rec && !a.Qux) LAUNCH_G(NX_, NU_, MODE_, false, true, false);          \
         else if (a.rec) LAUNCH_G(NX_, NU_, MODE_, false, true, true);                       \
         else LAUNCH_G(NX_, NU_, MODE_, false, false, true);                                 \
     }
