@@ -118,6 +118,7 @@ int launch_project(const isls_project_args &a, hipStream_t s)
     const int threads = ((a.R + 63) / 64) * 64;
 #define CALL(D_)                                                                                              \
     if (threads <= 256) hipLaunchKernelGGL((project_rows_kernel<T, D_, 256>), dim3(a.P), dim3(threads), 0, s, p); \
+    else if (threads <= 512) hipLaunchKernelGGL((project_rows_kernel<T, D_, 512>), dim3(a.P), dim3(threads), 0, s, p); /* 256 VGPRs: no spills at fp64 */ \
     else hipLaunchKernelGGL((project_rows_kernel<T, D_, 1024>), dim3(a.P), dim3(threads), 0, s, p)
     switch (a.d) {
         case 1: CALL(1); break;

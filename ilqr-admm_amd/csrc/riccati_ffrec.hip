@@ -514,7 +514,7 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
     static const bool v2_on = [] { const char *e = getenv("ISLS_FF_V2"); return !e || atoi(e) != 0; }();
 #define LAUNCH2(NX_, NU_, MODE_)                                                                                        \
     {                                                                                                                   \
-        if (segmented) hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEG_DEPTH, 2, MODE_>), dim3(grid, p.nseg), dim3(64), 0, s, p); \
+        if (segmented) hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEG_DEPTH, (NX_ * NX_ > 64 ? 1 : 2), MODE_>), dim3(grid, p.nseg), dim3(64), 0, s, p); /* n = 9: 256 registers spill */ \
         else hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEQ_DEPTH, 1, MODE_>), dim3(grid), dim3(64), 0, s, p);                 \
     }
 #define CALL(NX_, NU_)                                                                                                  \

@@ -221,6 +221,7 @@ int launch_sls_admm(const isls_sls_admm_args &a, hipStream_t s)
     const size_t smem = (size_t)a.R * a.D * sizeof(T);
 #define CALL(D_)                                                                                                  \
     if (threads <= 256) hipLaunchKernelGGL((sls_admm_kernel<T, D_, 256>), dim3(a.P), dim3(threads), smem, s, p);  \
+    else if (threads <= 512) hipLaunchKernelGGL((sls_admm_kernel<T, D_, 512>), dim3(a.P), dim3(threads), smem, s, p); \
     else hipLaunchKernelGGL((sls_admm_kernel<T, D_, 1024>), dim3(a.P), dim3(threads), smem, s, p)
     switch (a.D) {
         case 1: CALL(1); break;
