@@ -367,11 +367,31 @@ __global__ __launch_bounds__(1024) void reduce_kernel(int B, const T *cost, cons
     }
     __shared__ T sm[5][16];                                   // one partial per wavefront of the 1024-thread workgroup
     T cs = T(0), pm = T(0), dm = T(0), na = T(0), nf = T(0);
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        if (cost) cs += cost[b];
-        if (res) { pm = res[2 * b] > pm ? res[2 * b] : pm; dm = res[2 * b + 1] > dm ? res[2 * b + 1] : dm; }
-        na += (active == nullptr || active[b] != 0) ? T(1) : T(0);
-        if (status) nf += status[b] != 0 ? T(1) : T(0);
+    // four trajectories per thread and trip, every load of the trip issued before the first use: the kernel is one workgroup
+    // of dependent loads, so the trips -- not the bytes -- are its time (the sums keep their order: b ascending per thread)
+    constexpr int U = 4;
+    for (int b0 = threadIdx.x; b0 < B; b0 += U * blockDim.x) {
+        T c[U], r0[U], r1[U];
+        int ac[U], st[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int b = b0 + q * (int)blockDim.x, bc = b < B ? b : B - 1;
+            c[q] = cost ? cost[bc] : T(0);
+            r0[q] = res ? res[2 * bc] : T(0);
+            r1[q] = res ? res[2 * bc + 1] : T(0);
+            ac[q] = active ? active[bc] : 1;
+            st[q] = status ? status[bc] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (b0 + q * (int)blockDim.x < B) {
+                cs += c[q];
+                pm = r0[q] > pm ? r0[q] : pm;
+                dm = r1[q] > dm ? r1[q] : dm;
+                na += ac[q] != 0 ? T(1) : T(0);
+                nf += st[q] != 0 ? T(1) : T(0);
+            }
+        }
     }
     cs = wave_sum(cs); na = wave_sum(na); nf = wave_sum(nf); pm = wave_max(pm); dm = wave_max(dm);
     const int w = threadIdx.x / kWave;
