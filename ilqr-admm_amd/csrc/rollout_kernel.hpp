@@ -65,6 +65,8 @@ struct RoP {
 };
 
 // ---- built-in forward models -------------------------------------------------
+__device__ __forceinline__ void sin_cos(double a, double &s, double &c) { sincos(a, &s, &c); }
+__device__ __forceinline__ void sin_cos(float a, float &s, float &c) { sincosf(a, &s, &c); }
 template <typename T, int NX, int NU, int MODEL>
 struct Model;
 
@@ -126,8 +128,10 @@ struct Model<T, 9, 3, ISLS_MODEL_ARM3R> {      // planar 3R arm, state [q, qd, e
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             c += xn[j];
-            ex += cos(c);
-            ey += sin(c);
+            T sn, cs;
+            sin_cos(c, sn, cs);                               // one range reduction for both (the same values as sin / cos)
+            ex += cs;
+            ey += sn;
         }
         xn[6] = ex; xn[7] = ey; xn[8] = T(0);
     }
@@ -140,8 +144,10 @@ struct Model<T, 4, 2, ISLS_MODEL_CAR> {        // car-simple [x, y, theta, v]  (
     __device__ __forceinline__ void load(const T *par, T *, int, int) { dt = par[0]; }
     __device__ __forceinline__ void step(const T (&x)[4], const T (&u)[2], T (&xn)[4]) const
     {
-        xn[0] = x[0] + dt * x[3] * cos(x[2]);
-        xn[1] = x[1] + dt * x[3] * sin(x[2]);
+        T sn, cs;
+        sin_cos(x[2], sn, cs);
+        xn[0] = x[0] + dt * x[3] * cs;
+        xn[1] = x[1] + dt * x[3] * sn;
         xn[2] = py_mod(x[2] + dt * x[3] * u[0], T(2 * 3.14159265358979323846));
         xn[3] = x[3] + dt * u[1];
     }
@@ -155,10 +161,13 @@ struct Model<T, 4, 2, ISLS_MODEL_TASSA> {      // Tassa car-parking [x, y, theta
     __device__ __forceinline__ void step(const T (&x)[4], const T (&u)[2], T (&xn)[4]) const
     {
         const T f = dt * x[3];
-        const T sw = sin(u[0]) * f;
-        const T b = (f * cos(u[0]) + d) - sqrt(d * d - sw * sw);
-        xn[0] = x[0] + b * cos(x[2]);
-        xn[1] = x[1] + b * sin(x[2]);
+        T su, cu_, s2, c2;
+        sin_cos(u[0], su, cu_);
+        sin_cos(x[2], s2, c2);
+        const T sw = su * f;
+        const T b = (f * cu_ + d) - sqrt(d * d - sw * sw);
+        xn[0] = x[0] + b * c2;
+        xn[1] = x[1] + b * s2;
         xn[2] = x[2] + asin(sw / d);
         xn[3] = x[3] + u[1] * dt;
     }

@@ -188,6 +188,11 @@ class Engine:
             r = self._t(rho)
             if r.ndim == 2:
                 return r.reshape(1, d, d)
+            if r.ndim == 3 and bool((r == r[:1]).all()):
+                # given per step but the same at every step (compute_Rr_Qr's tiling of a matrix, isls/base.py:55-79): kept as
+                # one time-invariant block -- the kernels then hold the rows in registers instead of loading them per step,
+                # and the feed-forward pass takes its one-hand-off form
+                return r[:1].contiguous()
             return r                                   # [N,d,d] or [B,N,d,d]
 
         has_x, has_u = x_box is not None or x_sets is not None, u_box is not None or u_sets is not None
