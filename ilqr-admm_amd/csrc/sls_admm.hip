@@ -22,8 +22,11 @@ struct SlsP {
     int32_t *iters;
 };
 
+// Occupancy is the lever of this kernel (one workgroup per problem, the time in the per-row projection iterations): the
+// 256-thread form is held to 256 registers at fp64 (two workgroups per CU: measured 153 -> 268 it/s at DI-3D when the
+// projection code had grown past that line) and, for rows of three or four entries, to 128 at fp32 (four wavefronts per SIMD).
 template <typename T, int D, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void sls_admm_kernel(SlsP<T> p)
+__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 4 : 1) : 2) : 1)) void sls_admm_kernel(SlsP<T> p)
 {
     extern __shared__ __align__(16) unsigned char sls_smem[];
     T *rhs = reinterpret_cast<T *>(sls_smem);                  // [R][D]
