@@ -23,7 +23,7 @@ struct ProjP {
 // BLOCK = largest workgroup the instance is launched with: up to 256 threads (R <= 256, the usual case: rows = time
 // steps or N*m) a wave may use the whole register file; 1024-thread workgroups are capped at 128 VGPRs.
 template <typename T, int D, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void project_rows_kernel(ProjP<T> p)
+__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 2 : 1)) void project_rows_kernel(ProjP<T> p)
 {
     __shared__ T red[2][16];
     const int pb = blockIdx.x, r = threadIdx.x;
