@@ -140,6 +140,128 @@ __global__ __launch_bounds__(64) void columns_rollout_kernel(ColP<T> p)
     for (int r = 0; r < NU; ++r) du[(N - 1) * NU + r] = y[r];
 }
 
+// Row form of the same roll-out: lane = (problem, column, row of [K_t; A_t B_t]).  The column form above gives a lane the
+// whole n x (n + m) mat-vec of a step (135 dependent multiply-adds at n = 9, every operand a broadcast LDS read), B C lanes
+// in all -- 64 wavefronts for 1024 arms; here a lane owns ONE row: u-lane r forms u_r = k_r + K[r,:] x, x-lane a forms
+// x'_a = A[a,:] x + B[a,:] u, each from its own row, which it fetches itself (a contiguous run per lane, D steps ahead),
+// with x and u handed around through LDS twice per step.  n + m multiply-adds per lane and step, C (n + m) lanes per
+// problem (one problem per wavefront at n = 9, C = 4: as many wavefronts as problems).  The sums run in the order of the
+// column form: bit-identical results.
+template <typename T, int NX, int NU, int C>
+__global__ __launch_bounds__(64) void columns_rollout_rows_kernel(ColP<T> p)
+{
+    constexpr int W = NX + NU, GC = C * W, PB = kWave / GC, D = kColDepth;
+    static_assert(PB >= 1, "a problem's lanes fit one wavefront");
+    // per (problem slot, column): x[2][NX] (double buffer: x' is written while x is still being read) | u[NU]
+    constexpr int SL = 2 * NX + NU;
+    __shared__ T lds[(PB * C + 1) * SL];
+    const int lane = threadIdx.x;
+    const bool inslot = lane / GC < PB;
+    const int slot = inslot ? lane / GC : PB - 1;
+    const int li = inslot ? lane - slot * GC : GC - 1;         // surplus lanes repeat the last lane of the last slot
+    const int c = li / W, i = li - c * W;
+    const bool xl = i < NX;
+    const int r = xl ? 0 : i - NX;
+    const int b = blockIdx.x * PB + slot;
+    const bool valid = b < p.B && (!p.active || p.active[b]);
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return;
+    const int bsh = __builtin_amdgcn_readlane(b, __builtin_ctzll(vm));
+    const int bb = valid ? b : bsh;                            // a slot without a problem repeats the first valid one (loads only)
+    const int N = p.N;
+    const int64_t col = (int64_t)c * p.B + bb;
+    T *dx = p.dx + col * N * NX, *du = p.du + col * N * NU;
+    // the lane's row: x-lane a -> A_t[a,:] (NX words) and B_t[a,:] (NU words); u-lane r -> K_t[r,:] and k_t[r] (then padding)
+    const T *pa = xl ? p.A.at(bb, 0) + i * NX : p.K + (int64_t)bb * N * NU * NX + r * NX;
+    const int64_t sa = xl ? p.A.st : NU * NX;
+    const T *pbv = xl ? p.Bm.at(bb, 0) + i * NU : p.k + col * N * NU + r;
+    const int64_t sbv = xl ? p.Bm.st : NU;
+    const int nbv = xl ? NU : 1;                               // words of the second run this lane may read
+    T *st = lds + (slot * C + c) * SL;
+    T *const dump = lds + (PB * C) * SL;                       // two words for the publishes a lane must not make
+    T ra[D][NX], rb[D][NU];
+    auto fetch = [&](int tq, T (&fa)[NX], T (&fb)[NU]) {
+        const int t = __builtin_amdgcn_readfirstlane(tq < N - 1 ? tq : N - 2);
+        const T *qa = pa + (int64_t)t * sa, *qb = pbv + (int64_t)t * sbv;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) fa[j] = qa[j];
+#pragma unroll
+        for (int q = 0; q < NU; ++q) fb[q] = qb[q < nbv ? q : nbv - 1];
+    };
+    // x_0: zero for column 0, the unit vector e_{c-1} for column c >= 1
+    (xl ? st + i : dump)[0] = (xl && c >= 1 && i == c - 1) ? T(1) : T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        fetch(d, ra[d], rb[d]);
+        __builtin_amdgcn_sched_barrier(0);                     // issue order = consumption order
+    }
+    slot_sync();
+    // every lane stores one word per step: x-lane a the component x_t[a], u-lane r the control u_t[r] (slots without a
+    // problem store the shadowed problem's words again); dead steps past N-2 store into row N-1, which is rewritten below
+    T *const po = xl ? dx + i : du + r;
+    const int ps = xl ? NX : NU;
+    T *const udst = xl ? dump : st + 2 * NX + r;
+    const int xoff = xl ? i : 0;
+    for (int t0 = 0; t0 < N - 1; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 + d;
+            const bool on = t < N - 1;                         // uniform
+            const T *xc = st + (t & 1) * NX;
+            T x[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) x[j] = xc[j];
+            const T xown = xc[xoff];
+            T acc = xl ? T(0) : rb[d][0];                      // u-lane: k_r first, then K[r,:] x (the column form's order)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) acc += ra[d][j] * x[j];
+            T bv[NU];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) bv[q] = xl ? rb[d][q] : T(0);
+            fetch(t + D, ra[d], rb[d]);
+            udst[0] = acc;                                     // u-lanes publish u_r (x-lanes: a dump word)
+            slot_sync();
+            T u[NU];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) u[q] = st[2 * NX + q];
+            T accx = acc;
+#pragma unroll
+            for (int q = 0; q < NU; ++q) accx += bv[q] * u[q]; // x-lanes: + B[a,:] u ; u-lanes: + 0
+            po[(int64_t)(on ? t : N - 1) * ps] = xl ? xown : acc;
+            // x' into the other buffer (a dead step carries x over); u-lanes write the second dump word
+            (xl ? st + ((t + 1) & 1) * NX + i : dump + 1)[0] = on ? accx : xown;
+            slot_sync();
+        }
+    }
+    if (!valid) return;
+    // x_{N-1}: after the loop the current buffer index is that of the first step not executed
+    const int tend = ((N - 1 + D - 1) / D) * D;                // steps the loop walked (dead ones included)
+    const T *xf = st + (tend & 1) * NX;
+    if (xl) dx[(N - 1) * NX + i] = xf[i];
+    if (i != 0) return;
+    // last control: minimiser of its own cost term  (R + Rr) du = R ud + Rr u_reg  (isls.py:560-571, last block row)
+    T g[NU], H[NU][NU], U[NU][NU], rd[NU], y[NU];
+    const T *Cl = p.Cuu.at(b, N - 1);
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        g[q] = c == 0 ? -p.c0u.at(b, N - 1)[q] : T(0);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) H[q][j] = Cl[q * NU + j];
+    }
+    if (p.Rr.p) {
+        const T *Rl = p.Rr.at(b, N - 1);
+        const T *z = p.zu + col * N * NU + (N - 1) * NU, *l = p.lu + col * N * NU + (N - 1) * NU;
+#pragma unroll
+        for (int q = 0; q < NU; ++q)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) g[q] += T(2) * Rl[q * NU + j] * (z[j] - l[j]);
+    }
+    chol_upper<NU>(H, U, rd);
+    chol_solve<NU>(U, rd, g, y);
+#pragma unroll
+    for (int q = 0; q < NU; ++q) du[(N - 1) * NU + q] = y[q];
+}
+
 template <typename T>
 int launch_columns_rollout(const isls_columns_args &a, hipStream_t s)
 {
@@ -153,12 +275,23 @@ int launch_columns_rollout(const isls_columns_args &a, hipStream_t s)
     p.K = (const T *)a.K; p.k = (const T *)a.k; p.zu = (const T *)a.zu; p.lu = (const T *)a.lu;
     p.dx = (T *)a.dx; p.du = (T *)a.du; p.active = a.active;
     const int pb = 4, blocks = (a.B + pb - 1) / pb;
+    static const bool rows_on = [] { const char *e = getenv("ISLS_COL_ROWS"); return !e || atoi(e) != 0; }();
+#define LAUNCH_C(NX_, NU_, C_)                                                                                         \
+    {                                                                                                                  \
+        if constexpr (C_ * (NX_ + NU_) <= 64) {                                                                        \
+            if (rows_on) {                                                                                             \
+                constexpr int PBR = 64 / (C_ * (NX_ + NU_));                                                           \
+                hipLaunchKernelGGL((columns_rollout_rows_kernel<T, NX_, NU_, C_>), dim3((a.B + PBR - 1) / PBR), dim3(64), 0, s, p); \
+            } else hipLaunchKernelGGL((columns_rollout_kernel<T, NX_, NU_, C_>), dim3(blocks), dim3(64), 0, s, p);     \
+        } else hipLaunchKernelGGL((columns_rollout_kernel<T, NX_, NU_, C_>), dim3(blocks), dim3(64), 0, s, p);         \
+    }
 #define CALL(NX_, NU_)                                                                                               \
-    if (a.C == 2) hipLaunchKernelGGL((columns_rollout_kernel<T, NX_, NU_, 2>), dim3(blocks), dim3(64), 0, s, p);      \
-    else if (a.C == 3) hipLaunchKernelGGL((columns_rollout_kernel<T, NX_, NU_, 3>), dim3(blocks), dim3(64), 0, s, p); \
-    else hipLaunchKernelGGL((columns_rollout_kernel<T, NX_, NU_, 4>), dim3(blocks), dim3(64), 0, s, p)
+    if (a.C == 2) LAUNCH_C(NX_, NU_, 2)                                                                               \
+    else if (a.C == 3) LAUNCH_C(NX_, NU_, 3)                                                                          \
+    else LAUNCH_C(NX_, NU_, 4)
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
+#undef LAUNCH_C
     return check_launch();
 }
 template int launch_columns_rollout<double>(const isls_columns_args &, hipStream_t);

@@ -145,32 +145,42 @@ class ColumnSolver:
 
 
 class _LaggedAny:
-    """`bool(mask.any())` one iteration late: the flag of iteration j is copied to pinned host memory without blocking and
-    read while iteration j + 1 is already queued, so the host's launch work overlaps the kernels of the previous iteration
-    instead of waiting for them (a device sync per ADMM iteration made `isls_admm` host-bound: 1.19 ms per iteration for
-    0.65 ms of kernels).  The loop may run one iteration more than the reference's `break` -- with every problem inactive
-    the kernels of that iteration touch nothing."""
+    """`bool(mask.any())` without a device sync: the flag of every iteration is copied to pinned host memory behind the
+    iteration's kernels, and the loop only LOOKS at flags whose copy has already landed (`event.query()`), so the host keeps
+    queueing iterations ahead of the GPU instead of waiting for each one (a device sync per ADMM iteration made `isls_admm`
+    host-bound: 1.19 ms per iteration for 0.65 ms of kernels).  The loop may therefore run a few iterations more than the
+    reference's `break` -- with every problem inactive the kernels of those iterations touch nothing; `dead_rows()` tells
+    afterwards which iterations they were."""
 
-    def __init__(self, device):
-        self.host = torch.ones(2, dtype=torch.int32).pin_memory()
-        self.ev = [torch.cuda.Event(), torch.cuda.Event()]
-        self.dev = torch.ones(2, dtype=torch.int32, device=device)
-        self.n = 0
+    def __init__(self, device, n):
+        self.host = torch.ones(max(1, n), dtype=torch.int32).pin_memory()
+        self.dev = torch.ones(max(1, n), dtype=torch.int32, device=device)
+        self.ev = []
 
     def push(self, mask):
-        i = self.n & 1
+        i = len(self.ev)
         self.dev[i] = mask.any()
         self.host[i:i + 1].copy_(self.dev[i:i + 1], non_blocking=True)
-        self.ev[i].record()
-        self.n += 1
+        e = torch.cuda.Event()
+        e.record()
+        self.ev.append(e)
 
-    def previous_all_inactive(self):
-        """True when the mask pushed one call before the last one was all zero."""
-        if self.n < 2:
-            return False
-        i = (self.n - 2) & 1
-        self.ev[i].synchronize()
-        return int(self.host[i]) == 0
+    def seen_all_inactive(self):
+        """True when a flag that has already arrived says that no problem was active after its iteration."""
+        for i, e in enumerate(self.ev):
+            if not e.query():
+                break
+            if int(self.host[i]) == 0:
+                return True
+        return False
+
+    def dead_rows(self):
+        """Iterations that ran although an earlier one had left no problem active (their log rows are not the reference's)."""
+        if not self.ev:
+            return []
+        self.ev[-1].synchronize()
+        first = next((i for i in range(len(self.ev)) if int(self.host[i]) == 0), None)
+        return [] if first is None else list(range(first + 1, len(self.ev)))
 
 
 def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=False, max_admm_iter=20, k_max=20,
@@ -208,7 +218,7 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
         self._expand_regularised(get_Cs)                                        # built-in cost on the device, else the caller's get_Cs (isls.py:548-560)
         cs.prepare(e.outer_active)
         cs.restart(e.outer_active)                                              # lmb restarts, z is warm-started (isls.py:613-616)
-        lag = _LaggedAny(e.device)
+        lag = _LaggedAny(e.device, J)
         act = e.admm_active
 
         def admm_iteration():
@@ -255,9 +265,10 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
                 break
             logbuf[j].copy_(e.res)
             lag.push(act)
-            if lag.previous_all_inactive():
-                logbuf[j].zero_()                                               # this iteration ran on no problem: no log row
+            if lag.seen_all_inactive():
                 break
+        for jd in lag.dead_rows():
+            logbuf[jd].zero_()                                                  # ran on no problem: no log row
         # new nominal: x_nom + d_x, u_nom + d_u of the last x-step (isls.py:684-687); the setter evaluates its cost
         oa = mask3(e.outer_active)
         e.xhat.copy_(torch.where(oa, e.xhat + dx[0], e.xhat))
