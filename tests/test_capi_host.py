@@ -175,3 +175,37 @@ def test_bench_refuses_more_gpus_than_devices():
                        timeout=300)
     assert r.returncode != 0 and "--gpus 64" in r.stderr and "device" in r.stderr
     assert not r.stdout.strip()
+
+
+def test_hot_path_kernels_keep_their_registers():
+    """Resource table of the built library (tools/scan_kernels.py reads the gfx950 code objects, no GPU): the kernels of
+    the headline outer iteration (n = 6, m = 3, fp64) and of config 5 hold their per-step state in registers.  Scratch
+    inside a step loop halves these kernels ('occupancy steps and spills'); the roll-out's few spilled words
+    sit outside its time loops, so it gets a small allowance instead of zero."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import scan_kernels
+    finally:
+        sys.path.pop(0)
+    tab = scan_kernels.kernel_table(capi.library_path() if hasattr(capi, "library_path") else scan_kernels.DEFAULT_LIB)
+    assert len(tab) > 600
+
+    def pick(prefix):
+        hit = {k: v for k, v in tab.items() if k.startswith("_ZN4isls" + prefix)}
+        assert hit, prefix
+        return hit
+    for prefix in ("19riccati_gain_kernelIdLi6ELi3E", "21riccati_ffrec2_kernelIdLi6ELi3E", "20riccati_ffrec_kernelIdLi6ELi3E",
+                   "17riccati_ff_kernelIdLi6ELi3E", "18admm_update_kernelId", "13expand_kernelId", "16linearize_kernelId",
+                   "27columns_rollout_rows_kernel", "19columns_admm_kernel"):
+        for k, v in pick(prefix).items():
+            assert v["scratch"] == 0, (k, v)
+    for k, v in pick("14rollout_kernelIdLi6ELi3ELi3E").items():        # the headline's double-integrator roll-out
+        assert v["scratch"] <= 64 and v["vgpr"] <= (256 if k.endswith("Li2EEEvNS_3RoPIT_EE") else 512), (k, v)
+    for prec, d in (("f", (1, 2, 3, 4)), ("d", (1,))):                 # config 5 in the widths that run at 256 threads
+        for D in d:
+            for fam in ("15sls_admm_kernelI", "19project_rows_kernelI"):
+                v = pick(f"{fam}{prec}Li{D}ELi256E")
+                (k, r), = v.items()
+                assert r["scratch"] <= (160 if prec == "f" and D >= 3 and fam.startswith("15") else 0), (k, r)
