@@ -30,6 +30,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 EVENT_PERIOD = 4               # kernel-family durations are sampled on every 4th timed step
+# ISLS_BENCH_REHEARSAL=1: the N>1 code path on a box with ONE device -- every rank drives cuda:0 and the collectives go over
+# gloo (RCCL refuses two ranks on one device).  The line it prints says so ("rehearsal": true) and is not a measurement.
+REHEARSAL = os.environ.get("ISLS_BENCH_REHEARSAL", "0") == "1"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 KIND_NAMES = ["riccati_gain_kernel", "riccati_ff_kernel", "rollout_kernel", "admm_update_kernel", "ff_prepare_kernel"]
 # kernels behind each timed family (isls_timing kind): the time-parallel feed-forward pass is two launches
@@ -97,7 +100,7 @@ def spawn_ranks(n_gpus):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n_gpus:
+    if have < n_gpus and not REHEARSAL:
         sys.exit(f"bench.py: --gpus {n_gpus} requested but only {have} HIP device(s) are visible; refusing to print a "
                  f"{n_gpus}-GPU line from fewer devices")
     with socket.socket() as so:                                # a free rendezvous port on the loopback interface
@@ -140,6 +143,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if REHEARSAL:
+        local_rank = 0                                        # every rank on the one device of a test box, table over gloo
     if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
         sys.exit(f"bench.py: rank {rank} needs device {local_rank}, only {torch.cuda.device_count()} HIP device(s) visible")
     dist = None
@@ -147,7 +152,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if REHEARSAL:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -155,7 +163,7 @@ def main():
     import isls_problems as P
     from isls import _capi as capi
     from isls.engine import Engine, library
-    from isls.shard import allreduce_table
+    from isls.shard import TableExchange
 
     B, N, J, L = args.batch, args.horizon, args.J, args.L
     cfg = P.config2(batch=B, N=N, seed=rank)
@@ -173,7 +181,12 @@ def main():
         eng.A = torch.as_tensor(cfg["A"], device=dev).reshape(1, 1, n, n)
         eng.Bm = torch.as_tensor(cfg["B"], device=dev).reshape(1, 1, n, m)
     eng.build_outer(L, J, tol_abs=0.0, tol_rel=0.0)          # tolerances 0: no early exit, fixed work
-    red = torch.zeros(world, 5, dtype=torch.float64, device=dev)
+    # convergence table of every outer iteration: this shard's row + ONE asynchronous all-reduce (RCCL's own stream); the
+    # compute stream never waits for it, the host reads the table an iteration late (isls/shard.py::TableExchange)
+    xch = TableExchange(world, rank, torch.float64, dev)
+
+    def exchange():
+        xch.post(lambda table, r: eng.reduce(table=table, rank=r))
 
     def step():
         if not args.lti:
@@ -181,8 +194,7 @@ def main():
         eng.expand()                                          # Cxx,Cuu,c0x,c0u about the nominal
         eng.run_outer()                                       # gain + J x (ff, rollout, update), one C call
         eng.accept_x_step()                                   # nominal <- x-step, cost log (no stop rule)
-        eng.reduce(table=red, rank=rank)                      # this shard's row of the [W,5] table, one launch
-        allreduce_table(red, world)                           # the one collective: 5 doubles per rank (RCCL)
+        exchange()                                            # this shard's row of the [W,5] table (one launch) + the one collective
 
     lib = library()
     for _ in range(args.warmup):
@@ -199,17 +211,18 @@ def main():
         # few microseconds of queue bubbles (measured: 2.03 ms per step with events on every step, 1.89 without)
         lib.isls_timing_pause(timing, 0 if i % EVENT_PERIOD == 0 else 1)
         step()
+    xch.finish()                                             # every exchange of the timed region is inside it
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     eng._outer_args.timing = None
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    red_host = red.cpu().numpy()
+    red_host = xch.finish().cpu().numpy()
     hess_shared = bool(eng._shared_hessian())
 
     # ---- the same workload with A,B shared over batch and time (stride-0 views; SURVEY 8(d): "report both") ----
@@ -223,8 +236,7 @@ def main():
             eng.expand()
             eng.run_outer()
             eng.accept_x_step()
-            eng.reduce(table=red, rank=rank)
-            allreduce_table(red, world)
+            exchange()
 
         step_lti()
         if dist is not None:
@@ -233,12 +245,13 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step_lti()
+        xch.finish()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         dl = time.perf_counter() - t1
         if dist is not None:
-            tl = torch.tensor([dl], dtype=torch.float64, device=dev)
+            tl = torch.tensor([dl], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             dl = float(tl.item())
         lti_it_per_s = world * args.steps / dl
@@ -307,6 +320,8 @@ def main():
                             "max_dual": float(red_host[:, 2].max()), "active": float(red_host[:, 3].sum()),
                             "failed": float(red_host[:, 4].sum())},
         }
+        if REHEARSAL:
+            out["rehearsal"] = True                             # N ranks on one device over gloo: exercises the code path, measures nothing
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args, B, N, n, m, J, L)
         print(json.dumps(out))

@@ -209,3 +209,61 @@ def test_hot_path_kernels_keep_their_registers():
                 v = pick(f"{fam}{prec}Li{D}ELi256E")
                 (k, r), = v.items()
                 assert r["scratch"] <= (160 if prec == "f" and D >= 3 and fam.startswith("15") else 0), (k, r)
+
+
+def _exchange_rank(rank, world, port, posts, ret):
+    import torch
+    import torch.distributed as dist
+
+    from isls.shard import TableExchange, summarize
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    xch = TableExchange(world, rank, torch.float64, "cpu")
+    seen = []
+
+    def fill_for(i):
+        def fill(table, r):                                   # what Engine.reduce(table=, rank=) leaves: own row, zeros elsewhere
+            table.fill_(99.0)                                 # stale contents of the rotating table must not survive
+            table.zero_()
+            table[r] = torch.tensor([10.0 * i + r, i + 0.5 * r, i + 0.25 * r, 3.0 + r, float(i == 2 and r == 1)], dtype=torch.float64)
+        return fill
+    assert xch.finish() is None and xch.latest() is None
+    for i in range(posts):
+        xch.post(fill_for(i))
+        late = xch.latest(lag=1)                              # the host reads the table one iteration late
+        seen.append(None if late is None else late.clone().numpy())
+    last = xch.finish().clone()
+    ret[rank] = (seen, last.numpy(), summarize(last).numpy())
+    dist.destroy_process_group()
+
+
+def test_asynchronous_table_exchange_two_ranks():
+    """isls.shard.TableExchange (what bench.py posts after every outer iteration): the all-reduce is started without a wait,
+    tables rotate, a table is waited for before it is refilled, the host reads one iteration late; world 2 over gloo."""
+    import torch.multiprocessing as mp
+    world, posts = 2, 5
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_rank, args=(world, 29531, posts, ret), nprocs=world, join=True)
+
+    def expected(i):
+        return np.array([[10.0 * i + r, i + 0.5 * r, i + 0.25 * r, 3.0 + r, float(i == 2 and r == 1)] for r in range(world)])
+    for r in range(world):
+        seen, last, total = ret[r]
+        assert seen[0] is None
+        for i in range(1, posts):
+            assert np.array_equal(seen[i], expected(i - 1)), (r, i)
+        assert np.array_equal(last, expected(posts - 1))
+        e = expected(posts - 1)
+        assert np.array_equal(total, [e[:, 0].sum(), e[:, 1].max(), e[:, 2].max(), e[:, 3].sum(), e[:, 4].sum()])
+
+
+def test_table_exchange_single_rank_needs_no_process_group():
+    import torch
+
+    from isls.shard import TableExchange
+    xch = TableExchange(1, 0, torch.float64, "cpu")
+    for i in range(3):
+        t = xch.post(lambda table, r, i=i: table.copy_(torch.full((1, 5), float(i), dtype=torch.float64)))
+        assert float(t[0, 0]) == i
+    assert float(xch.latest(lag=1)[0, 0]) == 1.0 and float(xch.finish()[0, 0]) == 2.0

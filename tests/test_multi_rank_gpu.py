@@ -51,7 +51,7 @@ def _rank_main(rank, world, port, ret):
     import torch
     import torch.distributed as dist
 
-    from isls.shard import allreduce_table, shard_range, summarize
+    from isls.shard import TableExchange, allreduce_table, shard_range, summarize
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(B_GLOBAL, rank, world)
@@ -59,6 +59,11 @@ def _rank_main(rank, world, port, ret):
     eng = _solve_shard(lo, hi, table, rank)
     own = table.cpu()
     gathered = allreduce_table(own.clone(), world)           # gloo: the 40-byte-per-rank all-reduce, staged through the host
+    # the same exchange the way bench.py posts it: asynchronous, on the device table, rotating buffers
+    xch = TableExchange(world, rank, torch.float64, "cuda:0")
+    for _ in range(3):
+        xch.post(lambda t, r: eng.reduce(table=t, rank=r))
+    assert torch.equal(xch.latest(lag=1).cpu(), gathered) and torch.equal(xch.finish().cpu(), gathered)
     ret[rank] = dict(x=eng.xhat.cpu().numpy(), u=eng.uhat.cpu().numpy(), cost=eng.cost.cpu().numpy(),
                      own=own.numpy(), table=gathered.numpy(), total=summarize(gathered).numpy())
     dist.destroy_process_group()
@@ -90,3 +95,23 @@ def test_two_ranks_on_the_hip_path_match_single_process():
         assert np.array_equal(table[r], own[r])
         assert abs(total[0] - full[0]) <= 1e-12 * abs(full[0])                       # sum of shard sums vs one sum
         assert np.array_equal(total[1:], full[1:])                                   # maxima and counts are exact
+
+
+def test_bench_two_rank_rehearsal():
+    """`bench.py --gpus 2` end to end on the one device of the test box (ISLS_BENCH_REHEARSAL=1: both ranks on cuda:0, the
+    table over gloo): the launcher spawns its ranks as child processes, every rank runs the timed loop with the asynchronous
+    table exchange, rank 0 prints ONE line that says n_gpus = 2 and carries both shards in its convergence summary."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ISLS_BENCH_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "300",
+                        "--horizon", "40"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["convergence"]["active"] == 600.0 and out["convergence"]["failed"] == 0.0
+    assert out["value"] > 0 and "cpu_baseline" not in out

@@ -81,7 +81,7 @@ def kernel_table(path=DEFAULT_LIB):
 
 def demangle(names):
     try:
-        r = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True, check=True)
+        r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True)
         return r.stdout.split("\n")[:len(names)]
     except Exception:
         return list(names)
