@@ -9,7 +9,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer into caller-owned memory (torch tensors in our host code);
  *     the library allocates no device memory, keeps no global state, and is re-entrant per stream
- *     (tuning overrides read from the environment, ISLS_*_TPW / ISLS_FF_*, are the one process-wide input);
+ *     (the one process-wide input: experiment switches read from the environment once -- ISLS_*_TPW trajectories per
+ *     wavefront, ISLS_GAIN_FF=0 / ISLS_FF_V2=0 / ISLS_COL_ROWS=0 select the previous form of a kernel; results do not
+ *     depend on them beyond rounding);
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return value: ISLS_OK or a negative ISLS_ERR_* (argument / unsupported-size / launch error);
  *     numerical trouble is reported per trajectory in the int32 `status[B]` bit mask instead;
@@ -21,7 +23,8 @@
  *   - `active` (nullable) : trajectories with active[b]==0 are skipped entirely (frozen: converged
  *     or failed, SURVEY section 5 "failure detection").
  *
- * Supported (n,m): {2,1} {4,2} {6,3} {9,3} (the reference notebooks' systems); others ->
+ * Supported (n,m): {2,1} {4,2} {6,3} {9,3} (the reference notebooks' systems) and {3,1} {6,2} {2,2} {3,3} (with them every
+ * get_double_integrator_AB(nb_dim <= 3, nb_deriv <= 3) system); isls_dims_supported(n, m) answers for a pair, others ->
  * ISLS_ERR_UNSUPPORTED.  1 <= L <= 64.
  */
 #ifndef ISLS_HIP_H
