@@ -245,7 +245,12 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         T ra[JA], rb[JB], crow[W];
         T c0, hv, zv, lv;                                      // FF form
     };
-    Stage ring[D];
+#ifndef ISLS_GAIN_RING
+#define ISLS_GAIN_RING D
+#endif
+    constexpr int RD = ISLS_GAIN_RING;                          // steps of operands in flight (<= D: the unrolled group)
+    static_assert(RD >= 1 && RD <= D, "ring depth");
+    Stage ring[RD];
     auto fetch = [&](int tq, Stage &g) {
         const int t = __builtin_amdgcn_readfirstlane(tq);      // uniform: the offsets below are scalar arithmetic
         const int64_t oa = (int64_t)t * a_st, ob = (int64_t)t * b_st;
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         }
     };
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < RD; ++d) {
         fetch(N - 2 - d > 0 ? N - 2 - d : 0, ring[d]);          // unconditional (clamped): exact vmcnt bookkeeping
         __builtin_amdgcn_sched_barrier(0);                      // issue order = consumption order
     }
@@ -348,9 +353,18 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         // Everything the step reads from the slot's V and [A B] goes into registers in ONE batch of LDS reads (a lone wavefront
         // pays the full LDS latency at every wait: read-a-little / compute-a-little costs that latency ~50 times per step)
         // V first; the rows of [A B] are requested one by one as the rows of V are used up, so they arrive while (1) computes
-        // and both are never in registers in full.  Where V and [A B] together exceed ~200 registers (n = 9) only AHEAD rows
-        // are in flight at a time -- the whole batch would spill into scratch memory.
-        constexpr int AHEAD = (NX * NX + NX * W <= 100) ? NX : 2;
+        // and both are never in registers in full.  AHEAD rows are in flight at a time: the whole of V (AHEAD = NX) costs
+        // registers for nothing -- two rows ahead cover the LDS latency just as well (n = 6 alone: 182 -> 171 us; with the
+        // feed-forward recursion inside 2 / 3 / 4 / 6 rows measure the same, 3 kept) and at n = 9 the whole batch would
+        // spill into scratch memory.
+#ifndef ISLS_GAIN_AHEAD_FF
+#define ISLS_GAIN_AHEAD_FF 3
+#endif
+#ifndef ISLS_GAIN_AHEAD
+#define ISLS_GAIN_AHEAD 2
+#endif
+        constexpr int AHEAD_ = (NX * NX + NX * W <= 100) ? (FF ? ISLS_GAIN_AHEAD_FF : ISLS_GAIN_AHEAD) : 2;
+        constexpr int AHEAD = AHEAD_ < NX ? AHEAD_ : NX;
         T S[NX], colv[NX], Vr[NX][NX], Fr[NX][W];
 #pragma unroll
         for (int k = 0; k < NX; ++k) colv[k] = ABs[k * W + i];
@@ -415,7 +429,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 #pragma unroll
         for (int c = 0; c < W; ++c) M[c] = (c < NX) ? fma(g.crow[c], zmask, M[c]) : g.crow[c] + M[c];   // one rounding either way
         __builtin_amdgcn_sched_barrier(0);
-        fetch(t - D > 0 ? t - D : 0, g);                       // refill this ring entry (clamped, unconditional): ~1.5 steps ahead
+        fetch(t - RD > 0 ? t - RD : 0, g);                     // refill this ring entry (clamped, unconditional): ~RD - 0.5 steps ahead
         // (3) u-lanes publish their row of [Qux Quu] (x-lanes write the dump words)
 #pragma unroll
         for (int c = 0; c < W; ++c) rec[qdst + c] = M[c];
@@ -591,12 +605,12 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         --tb;
     }
     for (; tb - (D - 1) >= 0; tb -= D) {
-        step(tb, ring[1], 1, std::true_type{});
+        step(tb, ring[RD - 1], 1, std::true_type{});
         step(tb - 1, ring[0], 0, std::true_type{});
         tlast = tb - 1;
     }
     if (tb >= 0) {                                             // one more step (tb == 0)
-        step(tb, ring[1], 1, std::true_type{});
+        step(tb, ring[RD - 1], 1, std::true_type{});
         tlast = tb;
     }
 #ifndef ISLS_GAIN_EXP_NOFLUSH
