@@ -52,6 +52,30 @@ __device__ __forceinline__ void static_for(F &&f)
 // ds_read needs no s_barrier and, crucially, no `s_waitcnt vmcnt(0)`: __syncthreads() would drain the
 // global loads that are deliberately kept in flight several steps ahead.  This only pins the compiler's
 // ordering of memory operations (wavefront-scope fences and a wave barrier emit no instructions).
+// Streaming accesses (the `nt` bit of a gfx950 global load / store): data a launch touches once -- the packed records of a
+// feed-forward pass, the arrays a pass writes for a later launch -- should not push the re-used lines (the vectors a
+// recursion walks 8 bytes at a time, the gains the winner replay reads again) out of the L2.  Measured per site
+// (tools/kbench.py): the switches default to what paid.
+template <typename V>
+__device__ __forceinline__ V ld_stream(const V *p) { return __builtin_nontemporal_load(p); }
+template <typename V>
+__device__ __forceinline__ void st_stream(V *p, V v) { __builtin_nontemporal_store(v, p); }
+#ifndef ISLS_NT_FFREC
+#define ISLS_NT_FFREC 1
+#endif
+#ifndef ISLS_NT_GAIN_LD
+#define ISLS_NT_GAIN_LD 0
+#endif
+#ifndef ISLS_NT_GAIN_ST
+#define ISLS_NT_GAIN_ST 1
+#endif
+#ifndef ISLS_NT_RO_LD
+#define ISLS_NT_RO_LD 0
+#endif
+#ifndef ISLS_NT_LIN_ST
+#define ISLS_NT_LIN_ST 0
+#endif
+
 __device__ __forceinline__ void slot_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

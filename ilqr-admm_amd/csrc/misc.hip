@@ -148,6 +148,14 @@ struct LinP {
     const int32_t *active;
 };
 
+// A_t, B_t are written for the NEXT launch (the gain pass) and never read here
+template <typename T>
+__device__ __forceinline__ void lin_st(T *p, T v)
+{
+    if constexpr (ISLS_NT_LIN_ST) st_stream(p, v);
+    else *p = v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void linearize_kernel(LinP<T> p)
 {
@@ -160,19 +168,19 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinP<T> p)
     const int64_t bN = (int64_t)b * N;
     T *A = p.A + bN * n * n, *Bm = p.Bm + bN * n * m;
     if (p.model == ISLS_MODEL_LTI) {
-        for (int e = lane; e < N * n * n; e += kWave) A[e] = par[e % (n * n)];
-        for (int e = lane; e < N * n * m; e += kWave) Bm[e] = par[n * n + e % (n * m)];
+        for (int e = lane; e < N * n * n; e += kWave) lin_st(&A[e], par[e % (n * n)]);
+        for (int e = lane; e < N * n * m; e += kWave) lin_st(&Bm[e], par[n * n + e % (n * m)]);
         return;
     }
     if (p.model == ISLS_MODEL_DI) {
         const int d = n / 2;
         for (int e = lane; e < N * n * n; e += kWave) {
             const int r = (e % (n * n)) / n, c = e % n;
-            A[e] = (r == c) ? T(1) : ((r < d && c == r + d) ? par[0] : T(0));
+            lin_st(&A[e], (r == c) ? T(1) : ((r < d && c == r + d) ? par[0] : T(0)));
         }
         for (int e = lane; e < N * n * m; e += kWave) {
             const int r = (e % (n * m)) / m, c = e % m;
-            Bm[e] = (r == c) ? par[1] : ((r == c + d) ? par[2] : T(0));
+            lin_st(&Bm[e], (r == c) ? par[1] : ((r == c + d) ? par[2] : T(0)));
         }
         return;
     }

@@ -255,9 +255,9 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         const int t = __builtin_amdgcn_readfirstlane(tq);      // uniform: the offsets below are scalar arithmetic
         const int64_t oa = (int64_t)t * a_st, ob = (int64_t)t * b_st;
 #pragma unroll
-        for (int j = 0; j < JA; ++j) g.ra[j] = pA[j][oa];
+        for (int j = 0; j < JA; ++j) g.ra[j] = ISLS_NT_GAIN_LD ? ld_stream(pA[j] + oa) : pA[j][oa];
 #pragma unroll
-        for (int j = 0; j < JB; ++j) g.rb[j] = pB[j][ob];
+        for (int j = 0; j < JB; ++j) g.rb[j] = ISLS_NT_GAIN_LD ? ld_stream(pB[j] + ob) : pB[j][ob];
         const T *cl = pcl + (int64_t)t * cl_st, *cr = pcr + (int64_t)t * cr_st;
 #pragma unroll
         for (int j = 0; j < NX; ++j) g.crow[j] = cl[j];
@@ -311,12 +311,20 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     T fk1[JK];
     auto send = [&](int tq, int j) {                           // j-th of the JP + JK stores of step tq's image
         if (j < JP) {
-            if constexpr (REC) *reinterpret_cast<V2 *>(recg + (int64_t)tq * (TPW * RW) + fw[j < JP ? j : 0]) = fl[j < JP ? j : 0];
+            if constexpr (REC) {
+                V2 *dr = reinterpret_cast<V2 *>(recg + (int64_t)tq * (TPW * RW) + fw[j < JP ? j : 0]);
+                if constexpr (ISLS_NT_GAIN_ST) st_stream(dr, fl[j < JP ? j : 0]);
+                else *dr = fl[j < JP ? j : 0];
+            }
         } else if (j < JP + JK) {
             const int jj = j - JP < JK ? (j - JP >= 0 ? j - JP : 0) : 0;
             T *dk = p.K + kgo[jj] + (int64_t)tq * (NU * NX);
-            if constexpr (KPAIRS) *reinterpret_cast<V2 *>(dk) = fk[jj];
-            else *dk = fk1[jj];
+            if constexpr (KPAIRS) {
+                if constexpr (ISLS_NT_GAIN_ST) st_stream(reinterpret_cast<V2 *>(dk), fk[jj]);
+                else *reinterpret_cast<V2 *>(dk) = fk[jj];
+            } else {
+                *dk = fk1[jj];
+            }
         }
     };
     // the JP + JK stores take evenly spaced places among the 3 NX blocks of the step's three accumulation loops

@@ -125,7 +125,10 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
     auto fetch = [&](int t, Stage &g) {
         const T *r = bR + (int64_t)t * BW;
 #pragma unroll
-        for (int j = 0; j < JR; ++j) g.rr[j] = *reinterpret_cast<const V2 *>(r + oR[j]);
+        for (int j = 0; j < JR; ++j) {
+            if constexpr (ISLS_NT_FFREC) g.rr[j] = ld_stream(reinterpret_cast<const V2 *>(r + oR[j]));
+            else g.rr[j] = *reinterpret_cast<const V2 *>(r + oR[j]);
+        }
         fetch_vec(t, g);
     };
     // cx_i / cu_i = c0 + 2 * (row of Qr/Rr) . d       (isls/sls.py:132-137; O2 of SURVEY 8c)
@@ -329,7 +332,10 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
         const int t = __builtin_amdgcn_readfirstlane(tq);
         const T *r = bR + (int64_t)t * BW;
 #pragma unroll
-        for (int j = 0; j < JR; ++j) g.rr[j] = *reinterpret_cast<const V2 *>(r + oR[j]);
+        for (int j = 0; j < JR; ++j) {                          // the records stream through once per pass: 78 -> 71 us with `nt`
+            if constexpr (ISLS_NT_FFREC) g.rr[j] = ld_stream(reinterpret_cast<const V2 *>(r + oR[j]));
+            else g.rr[j] = *reinterpret_cast<const V2 *>(r + oR[j]);
+        }
         g.c0 = pc0[(int64_t)t * c0st];
         g.hv = ph[(int64_t)t * hst];
         g.zv = pz[(int64_t)t * vst];

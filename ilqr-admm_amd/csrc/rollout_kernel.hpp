@@ -224,6 +224,27 @@ struct alignas(sizeof(T)) RoVec {
     T v[W];
 };
 
+// one staging load of the search (W adjacent words); ISLS_NT_RO_LD: as a streaming access
+template <typename T, int W>
+__device__ __forceinline__ RoVec<T, W> ro_load(const char *ptr)
+{
+    if constexpr (ISLS_NT_RO_LD) {
+        RoVec<T, W> r;
+        if constexpr (W == 2) {
+            typedef T V2 __attribute__((ext_vector_type(2)));
+            typedef V2 V2u __attribute__((aligned(sizeof(T))));
+            const V2 v = ld_stream(reinterpret_cast<const V2u *>(ptr));
+            r.v[0] = v.x;
+            r.v[1] = v.y;
+        } else {
+            r.v[0] = ld_stream(reinterpret_cast<const T *>(ptr));
+        }
+        return r;
+    } else {
+        return *reinterpret_cast<const RoVec<T, W> *>(ptr);
+    }
+}
+
 // CNT words of a record group (CNT even with pair loads: groups are padded) read back as aligned pairs: one ds_read_b128
 // per two doubles
 template <int W, int CNT, typename T>
@@ -418,6 +439,7 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
     }
 }
 
+#define ISLS_RO_LD(ptr) ro_load<T, W>(ptr)
 template <typename T, int NX, int NU, int MODEL, int JM, int OCC>
 __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
 {
@@ -548,8 +570,8 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
 #pragma unroll
         for (int d = 0; d < D; ++d) {
 #pragma unroll
-            for (int j = 0; j < JM; ++j) ra[d][j] = *reinterpret_cast<const Vec *>(ca[j]);
-            rb[d] = *reinterpret_cast<const Vec *>(cb);
+            for (int j = 0; j < JM; ++j) ra[d][j] = ISLS_RO_LD(ca[j]);
+            rb[d] = ISLS_RO_LD(cb);
             const int64_t adv = tf < N - 1 ? 1 : 0;
             tf += (int)adv;
 #pragma unroll
@@ -578,8 +600,8 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
         slot_sync();                                          /* record(t) visible to the slot */                           \
         if (!TAILF || t + D < N) {                            /* refill this ring entry with step t + D (the tail skips */  \
             _Pragma("unroll") for (int j = 0; j < JM; ++j)    /* fetches nobody consumes: the wave would wait for them)  */  \
-                ra[d][j] = *reinterpret_cast<const Vec *>(ca[j]);                                                           \
-            rb[d] = *reinterpret_cast<const Vec *>(cb);                                                                     \
+                ra[d][j] = ISLS_RO_LD(ca[j]);                                                                               \
+            rb[d] = ISLS_RO_LD(cb);                                                                                         \
             if (TAILF) {                                                                                                    \
                 const int64_t adv = tf < N - 1 ? 1 : 0;                                                                     \
                 tf += (int)adv;                                                                                             \
