@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (not part of the test suite: run once after kernel changes): the outer driver on the device
+(gain + first feed-forward pass in one launch, record feed-forward passes, roll-outs with the fused ADMM update) against
+the oracle's driver for random batch sizes, horizons, candidate counts and ADMM iteration counts of the double-integrator
+workload (config 2) in one to three dimensions.
+    python tools/random_sweep.py [--cases 60] [--seed 0]
+Prints the worst relative deviation over all cases; exits non-zero above 1e-9."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "ilqr-admm_amd"), ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+
+import isls_problems as P
+from dual import hip_kernels
+from helpers import outer_iteration_on_device
+from oracle import oracle as orc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    hip = hip_kernels()
+    okern, _ = orc.load()
+    worst, worst_case = 0.0, None
+    for c in range(a.cases):
+        B = int(rng.integers(1, 48))
+        N = int(rng.integers(2, 70))
+        L = int(rng.choice([1, 2, 3, 5, 8, 12, 20, 24, 33]))
+        J = int(rng.integers(1, 5))
+        seed = int(rng.integers(0, 1000))
+        cfg = P.config2(batch=B, N=N, seed=seed)
+        err = outer_iteration_on_device(cfg, range(B), hip, okern, L, J, cfg["rho_u"], cfg["relax"])
+        print(f"case {c:3d}: B={B:3d} N={N:3d} L={L:2d} J={J} seed={seed:3d}  err {err:.2e}", flush=True)
+        if not (err <= worst):
+            worst, worst_case = err, (B, N, L, J, seed)
+    print(f"worst {worst:.3e} at (B, N, L, J, seed) = {worst_case}")
+    return 0 if worst < 1e-9 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
