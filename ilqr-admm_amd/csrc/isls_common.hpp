@@ -72,9 +72,6 @@ __device__ __forceinline__ void st_stream(V *p, V v) { __builtin_nontemporal_sto
 #ifndef ISLS_NT_RO_LD
 #define ISLS_NT_RO_LD 0
 #endif
-#ifndef ISLS_NT_LIN_ST
-#define ISLS_NT_LIN_ST 0
-#endif
 
 __device__ __forceinline__ void slot_sync()
 {

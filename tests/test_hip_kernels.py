@@ -609,3 +609,34 @@ def test_short_horizons_through_the_record_path(dual, N):
     from helpers import outer_iteration_on_device
     err = outer_iteration_on_device(cfg, range(9), hip_kernels(), dk.oracle, 7, 3, cfg["rho_u"], cfg["relax"])
     assert err < 1e-10, f"N={N}: {err:.2e}"
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_state_independent_linearisation_patterns(oracle, dtype):
+    """`isls_linearize_*` for the models whose Jacobians do not depend on the state (dense LTI, double integrator): the
+    per-step [A | B] pattern is streamed out as 16-byte stores with running pattern indices -- odd and even matrix sizes, one
+    step, odd and even horizons, several trajectories with their own parameters, inactive trajectories left untouched; bit
+    for bit against the oracle (isls/sls_base.py:49-53, utils.get_double_integrator_AB)."""
+    import torch
+    from dual import hip_kernels
+    hip = hip_kernels()
+    np_t = np.float64 if dtype == "f64" else np.float32
+    rng = np.random.default_rng(3)
+    for (n, m) in [(2, 1), (3, 1), (3, 3), (4, 2), (6, 3), (9, 3)]:
+        for N in (1, 2, 7, 100):
+            for model in (capi.MODEL_LTI, capi.MODEL_DI):
+                if model == capi.MODEL_DI and n % 2:
+                    continue
+                B = 5
+                par = rng.standard_normal((B, n * n + n * m if model == capi.MODEL_LTI else 3)).astype(np_t)
+                x, u = np.zeros((B, N, n), np_t), np.zeros((B, N, m), np_t)
+                active = np.array([1, 0, 1, 1, 1], dtype=np.int32)
+                A0, B0 = np.full((B, N, n, n), 7.0, np_t), np.full((B, N, n, m), 7.0, np_t)
+                Ao, Bo = A0.copy(), B0.copy()
+                oracle.linearize(model, par, x, u, Ao, Bo, active=active)
+                Ad, Bd = torch.from_numpy(A0.copy()).cuda(), torch.from_numpy(B0.copy()).cuda()
+                hip.linearize(model, torch.from_numpy(par).cuda(), torch.from_numpy(x).cuda(), torch.from_numpy(u).cuda(), Ad, Bd,
+                              active=torch.from_numpy(active).cuda())
+                torch.cuda.synchronize()
+                assert np.array_equal(Ad.cpu().numpy(), Ao) and np.array_equal(Bd.cpu().numpy(), Bo), (n, m, N, model)
+                assert np.all(Ao[1] == 7.0) and np.all(Bo[1] == 7.0)
