@@ -91,8 +91,16 @@ class iSLS(Base):
         A, B = np.asarray(value[0], dtype=np.float64), np.asarray(value[1], dtype=np.float64)
         self.A, self.B = A, B
         e = self.engine
-        e.A = e._t(A)
-        e.Bm = e._t(B)
+        # a linearisation of the same shape as the one in use is copied INTO the buffers the engine already holds: argument blocks
+        # and captured HIP graphs (isls_admm) keep raw device pointers, and a get_AB callback delivers a fresh array per outer
+        # iteration -- replacing the tensors would leave those pointers on freed memory
+        for name, new in (("A", e._t(A)), ("Bm", e._t(B))):
+            old = getattr(e, name)
+            if old is not None and old.shape == new.shape and old.is_contiguous():
+                old.copy_(new)
+            else:
+                setattr(e, name, new)
+                e._outer_args = None
         self._user_AB = True
 
     @property

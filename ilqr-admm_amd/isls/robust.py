@@ -213,10 +213,20 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     device_only = not self._host_ls and all(blk is None or blk["desc"] is not None for blk in cs.blocks.values())
     graph = dict(g=None, eager_done=False) if (device_only and cs.constrained and e.profile_events is None and
                                                os.environ.get("ISLS_ADMM_GRAPH", "1") != "0") else None
+    def captured_pointers():
+        """device addresses a recorded ADMM iteration reads or writes through engine attributes a callback may replace"""
+        ts = [e.A, e.Bm, e.c0x, e.c0u, e.K, e.Qr, e.Rr, e.xhat, e.uhat, e.xx, e.xu, e.Qtab, e.ztab, e.model_par, e.cost_par,
+              cs.rec, cs.Cuu] + (list(e._seg_bufs) if getattr(e, "_seg_bufs", None) is not None and cs.seg is not None else [])
+        return tuple(None if t is None else t.data_ptr() for t in ts)
+
     for k in range(k_max):
         self._linearize(get_AB)
         self._expand_regularised(get_Cs)                                        # built-in cost on the device, else the caller's get_Cs (isls.py:548-560)
         cs.prepare(e.outer_active)
+        if graph is not None and graph["g"] is not None and graph["ptrs"] != captured_pointers():
+            # a buffer of the recorded iteration was re-allocated (e.g. a get_AB callback whose arrays changed shape): the
+            # graph holds the old addresses -- drop it, run eagerly once, record again
+            graph.update(g=None, eager_done=False)
         cs.restart(e.outer_active)                                              # lmb restarts, z is warm-started (isls.py:613-616)
         lag = _LaggedAny(e.device, J)
         act = e.admm_active
@@ -251,11 +261,17 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
                 try:
                     with torch.cuda.graph(g):
                         admm_iteration()
-                    graph["g"] = g
-                    g.replay()
-                except Exception:                                               # capture refused: stay on the eager path
+                except RuntimeError as exc:                                     # capture refused by the runtime: stay on the eager path
+                    # (IslsError / ValueError of a launch are bugs, not refusals: they propagate)
+                    if isinstance(exc, capi.IslsError):
+                        raise
+                    import warnings
+                    warnings.warn(f"isls_admm: HIP graph capture of the ADMM iteration failed ({exc}); running eagerly", RuntimeWarning)
                     graph = None
                     admm_iteration()
+                else:
+                    graph.update(g=g, ptrs=captured_pointers())
+                    g.replay()
             else:
                 admm_iteration()
                 if graph is not None:

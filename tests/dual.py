@@ -7,8 +7,13 @@ from isls import _capi as capi
 
 
 class DualKernels:
-    def __init__(self, oracle, hip, tol=1e-10, int_exact=True, verbose=False, ff_nseg=1, ff_record=False):
+    def __init__(self, oracle, hip, tol=1e-10, int_exact=True, verbose=False, ff_nseg=1, ff_record=False, ti_weights=False):
         self.oracle, self.hip, self.tol, self.int_exact, self.verbose = oracle, hip, tol, int_exact, verbose
+        # True: ADMM weights that are the same at every step ([N,d,d] / [N,d] tiles of one block, what compute_Rr_Qr builds from
+        # a scalar rho) reach the HIP side as ONE block ([1,d,d] / [1,d]: time stride 0), the way isls.Engine hands them over --
+        # the record feed-forward pass then takes its one-hand-off form (riccati_ffrec2_kernel) and the rollout keeps the AL
+        # weights in its record instead of loading them per step; the oracle still gets the tiled arrays
+        self.ti_weights = ti_weights
         # > 1: the HIP side runs the feed-forward pass in its time-parallel form (isls_ffseg: prepare + segmented
         # recursion + stitch) while the oracle keeps the reference's sequential recursion
         self.ff_nseg = ff_nseg
@@ -48,6 +53,11 @@ class DualKernels:
         dargs = [self._to_dev(a) for a in args]
         dkw = {k: self._to_dev(v) for k, v in kw.items()}
         getattr(self.oracle, name)(*args, **kw)
+        if self.ti_weights:
+            for key in ("Qr", "Rr", "wq", "wr"):
+                w = dkw.get(key)
+                if w is not None and w.ndim == (3 if key in ("Qr", "Rr") else 2) and w.shape[0] > 1 and bool((w == w[:1]).all()):
+                    dkw[key] = w[:1].contiguous()
         if name == "riccati_ff" and self.ff_nseg > 1:
             dkw = dict(dkw, seg=self._prepare_segments(dargs, dkw))
         if self.ff_record and name == "riccati_gain":

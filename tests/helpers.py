@@ -246,23 +246,26 @@ def tassa_arrays(g, bsel, dtype=np.float64):
     return d
 
 
-def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.0):
+def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.0, dtype="f64", outer_iters=1):
     """One outer DP-form iLQR-ADMM iteration through the library's own driver (`isls_ilqr_admm_outer_*`: gain pass with the
     first feed-forward pass inside, J x [ff -> rollout with the fused ADMM update]) on the device, and the same through the
-    oracle's driver on the host; returns the worst relative error over K, k, the x-step, z, lambda and the residuals."""
+    oracle's driver on the host; returns the worst relative error over K, k, the x-step, z, lambda and the residuals.
+    dtype "f64" / "f32" selects isls_ilqr_admm_outer_f64 / _f32 (and the oracle of the same precision); outer_iters > 1 repeats
+    the iteration (linearise + expand, driver call, accept) so that the gain pass also sees a moved nominal."""
     import torch
-    o = OracleDriver(oracle_kern, problem_arrays(cfg, bsel), rho_u=rho_u, relax=relax)
-    o.run_c(L, J)
-    h = OracleDriver(oracle_kern, problem_arrays(cfg, bsel), rho_u=rho_u, relax=relax)
+    f = np.float64 if dtype == "f64" else np.float32
+    o = OracleDriver(oracle_kern, problem_arrays(cfg, bsel, dtype=f), rho_u=rho_u, relax=relax, dtype=f)
+    for _ in range(outer_iters):
+        o.run_c(L, J)
+    h = OracleDriver(oracle_kern, problem_arrays(cfg, bsel, dtype=f), rho_u=rho_u, relax=relax, dtype=f)
     for k in [k for k, v in vars(h).items() if isinstance(v, np.ndarray)]:
         setattr(h, k, torch.from_numpy(getattr(h, k)).cuda())
     h.pa = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in h.pa.items()}
     h.kern = hip
     B, N, n, m = h.B, h.N, h.n, h.m
-    rec = torch.zeros(capi.ff_record_elems(B, N, n, m), dtype=torch.float64, device="cuda")
+    rec = torch.zeros(capi.ff_record_elems(B, N, n, m), dtype=torch.float64 if dtype == "f64" else torch.float32, device="cuda")
     pa, K = h.pa, capi.Kernels
-    alphas = torch.from_numpy(ALPHAS[:L].astype(np.float64)).cuda()
-    h.linearize_expand()
+    alphas = torch.from_numpy(ALPHAS[:L].astype(f)).cuda()
     gain = K.gain_args(h.A, h.Bm, h.Cxx, h.Cuu, h.K, None, None, None, status=h.status, active=h.admm_active, rec=rec)
     ff = K.ff_args(h.A, h.Bm, h.c0x, h.c0u, h.K, None, None, None, h.k, Rr=h.Rr[:1], xhat=h.xhat, uhat=h.uhat, zu=h.zu, lu=h.lu,
                    active=h.admm_active, rec=rec)
@@ -271,6 +274,9 @@ def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.
                         status=h.status, active=h.admm_active)
     admm = K.admm_args(h.xx, h.xu, h.res, zu=h.zu, lu=h.lu, u_lo=pa["u_lo"], u_hi=pa["u_hi"], relax=h.relax, tol_abs=0.0,
                        tol_rel=0.0, res_prev=h.res_prev, active=h.admm_active)
-    hip.outer(gain, ff, ro, admm, J, "f64", outer_active=h.outer_active)
+    for _ in range(outer_iters):
+        h.linearize_expand()
+        hip.outer(gain, ff, ro, admm, J, dtype, outer_active=h.outer_active)
+        hip.accept_step(h.xx, h.xu, h.cost_new, h.xhat, h.uhat, h.cost, outer_active=h.outer_active)
     torch.cuda.synchronize()
-    return max(rel_err(getattr(h, name).cpu().numpy(), getattr(o, name)) for name in ("K", "k", "xx", "xu", "zu", "lu", "res"))
+    return max(rel_err(getattr(h, name).cpu().numpy(), getattr(o, name)) for name in ("K", "k", "xx", "xu", "zu", "lu", "res", "xhat", "uhat", "cost"))

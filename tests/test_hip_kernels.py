@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def dual(oracle):
     from dual import DualKernels, hip_kernels
-    return lambda tol=1e-10, ff_nseg=1, ff_record=False: DualKernels(oracle, hip_kernels(), tol=tol, ff_nseg=ff_nseg,
-                                                                     ff_record=ff_record)
+    return lambda tol=1e-10, ff_nseg=1, ff_record=False, ti_weights=False: DualKernels(
+        oracle, hip_kernels(), tol=tol, ff_nseg=ff_nseg, ff_record=ff_record, ti_weights=ti_weights)
 
 
 def _report(dk):
@@ -237,6 +237,33 @@ def test_fp32_kernels(dual, ff_record, ff_nseg):
     dk.int_exact = False            # near-ties of the arg-min may flip in fp32
     d = OracleDriver(dk, pa, rho_u=cfg["rho_u"], relax=cfg["relax"], dtype=np.float32)
     d.run(2, 20, 3, 0.0)
+    _report(dk)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 1e-4)])
+@pytest.mark.parametrize("ff_nseg", [1, 3])
+@pytest.mark.parametrize("which", ["di3d_u", "di3d_xu", "car"])
+def test_one_handoff_feedforward_on_time_invariant_weights(dual, which, ff_nseg, dtype, tol):
+    """riccati_ffrec2_kernel -- the feed-forward pass the headline workload runs: packed records AND time-invariant ADMM
+    weights handed over as one [1,d,d] block (time stride 0), as isls.Engine does.  Kernel call by kernel call against the
+    oracle's four-term recursion on the tiled weights, sequential (ff_nseg = 1) and time-parallel (prepare + segments +
+    stitch), fp64 at 1e-10 and fp32 at the north star's 1e-4; the rollout reads its AL weights from the same one block."""
+    f = np.float64 if dtype == "f64" else np.float32
+    if which == "car":
+        cfg = P.config4(batch=8, N=200, seed=0)
+        pa, kw = problem_arrays(cfg, range(6), dtype=f), dict(rho_u=cfg["rho_u"])
+    else:
+        cfg = P.config2(batch=32, N=100, seed=5)
+        pa, kw = problem_arrays(cfg, range(11), dtype=f), dict(rho_u=cfg["rho_u"], relax=cfg["relax"])
+        if which == "di3d_xu":
+            pa["x_lo"] = np.full((100, 6), -np.inf, dtype=f); pa["x_hi"] = np.full((100, 6), np.inf, dtype=f)
+            pa["x_lo"][:, 3:6], pa["x_hi"][:, 3:6] = -1.2, 1.2
+            kw = dict(rho_x=0.05, rho_u=cfg["rho_u"], project_x=True, relax=1.5)
+    dk = dual(tol=tol, ff_nseg=ff_nseg, ff_record=True, ti_weights=True)
+    dk.int_exact = dtype == "f64"                                  # near-ties of the arg-min may flip in fp32
+    d = OracleDriver(dk, pa, dtype=f, **kw)
+    d.run(2, 20, 4, 0.0)
+    assert dk._rec is not None
     _report(dk)
 
 
@@ -496,33 +523,38 @@ def test_long_horizon_car(dual):
     _report(dk)
 
 
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 1e-4)])
 @pytest.mark.parametrize("mode,batch,with_x", [(capi.SOLVE_CHOL, 17, True), (capi.SOLVE_CHOL, 9, False), (capi.SOLVE_INV, 8, True)])
-def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x):
+def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x, dtype, tol):
     """isls_riccati_gain_ff_*: K and the first k of an outer iteration from ONE backward sweep (the way the reference's
     backward_pass_DP computes them, isls/isls.py:285-302) -- against the oracle's gain pass followed by its sequential
-    feed-forward pass; time-varying A, B per trajectory, ragged last wavefront, inactive trajectories untouched."""
+    feed-forward pass; time-varying A, B per trajectory, ragged last wavefront, inactive trajectories untouched.  Both
+    precisions of the exported entry point (include/isls_hip.h isls_riccati_gain_ff_f64 / _f32): 1e-10 / 1e-4."""
     import torch
     from dual import hip_kernels
     from helpers import rho_to_weights
     okern, hk = oracle, hip_kernels()
+    f = np.float64 if dtype == "f64" else np.float32
     rng = np.random.default_rng(3)
     cfg = P.config2(batch=batch, N=60, seed=2)
+    cfg = {k_: (v.astype(f) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k_, v in cfg.items()}
     N, n, m, B = 60, 6, 3, batch
-    z = lambda *s_: np.zeros(s_)   # noqa: E731
+    z = lambda *s_: np.zeros(s_, dtype=f)   # noqa: E731
+    rn = lambda *shape: rng.standard_normal(shape).astype(f)   # noqa: E731
     # general layout: per-trajectory, time-varying perturbations of the double integrator
-    A = np.tile(cfg["A"][None, None], (B, N, 1, 1)) + 0.02 * rng.standard_normal((B, N, n, n))
-    Bm = np.tile(cfg["B"][None, None], (B, N, 1, 1)) + 0.02 * rng.standard_normal((B, N, n, m))
-    Rr, Qr = rho_to_weights(cfg["rho_u"], N, m)[:1], (rho_to_weights(0.3, N, n)[:1] if with_x else None)   # [1,d,d]: time-invariant
-    xhat, uhat = rng.standard_normal((B, N, n)), 0.3 * rng.standard_normal((B, N, m))
-    zx, zu = rng.standard_normal((B, N, n)), rng.standard_normal((B, N, m))
-    lx, lu = 0.1 * rng.standard_normal((B, N, n)), 0.1 * rng.standard_normal((B, N, m))
+    A = np.tile(cfg["A"][None, None], (B, N, 1, 1)) + 0.02 * rn(B, N, n, n)
+    Bm = np.tile(cfg["B"][None, None], (B, N, 1, 1)) + 0.02 * rn(B, N, n, m)
+    Rr, Qr = rho_to_weights(cfg["rho_u"], N, m, f)[:1], (rho_to_weights(0.3, N, n, f)[:1] if with_x else None)   # [1,d,d]: time-invariant
+    xhat, uhat = rn(B, N, n), 0.3 * rn(B, N, m)
+    zx, zu = rn(B, N, n), rn(B, N, m)
+    lx, lu = 0.1 * rn(B, N, n), 0.1 * rn(B, N, m)
     Cxx, Cuu, c0x, c0u = z(B, N, n, n), z(B, N, m, m), z(B, N, n), z(B, N, m)
     okern.expand_quadratic(cfg["Qs"], cfg["zs"], cfg["seq"], cfg["u_std"], c0x, c0u, xhat=xhat, uhat=uhat, Cxx=Cxx, Cuu=Cuu,
                            Qr=np.tile(Qr, (N, 1, 1)) if with_x else None, Rr=np.tile(Rr, (N, 1, 1)))
     active = np.ones(B, dtype=np.int32)
     active[[1, B - 2]] = 0
-    K0 = rng.standard_normal((B, N, m, n))                      # what inactive trajectories must keep
-    k0 = rng.standard_normal((B, N, m))
+    K0 = rn(B, N, m, n)                      # what inactive trajectories must keep
+    k0 = rn(B, N, m)
     # oracle: gain, then the sequential feed-forward pass
     K, Quu, fac, Qux, k = K0.copy(), z(B, N, m, m), z(B, N, m, m), z(B, N, m, n), k0.copy()
     st = np.zeros(B, dtype=np.int32)
@@ -536,11 +568,11 @@ def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x):
                                       lu=lu, act=active, st=np.zeros(B, dtype=np.int32), Qr=Qr if with_x else None,
                                       zx=zx if with_x else None, lx=lx if with_x else None).items()}
     dK, dk_, dA, dB, dact, dst, dQr = d["K"], d["k"], d["A"], d["Bm"], d["act"], d["st"], d["Qr"]
-    rec = torch.full((capi.ff_record_elems(B, N, n, m),), float("nan"), dtype=torch.float64, device="cuda")
+    rec = torch.full((capi.ff_record_elems(B, N, n, m),), float("nan"), dtype=torch.float64 if dtype == "f64" else torch.float32, device="cuda")
     g = capi.Kernels.gain_args(dA, dB, d["Cxx"], d["Cuu"], dK, None, None, None, solve_mode=mode, status=dst, active=dact, rec=rec)
     ff = capi.Kernels.ff_args(dA, dB, d["c0x"], d["c0u"], dK, None, None, None, dk_, Qr=dQr, Rr=d["Rr"], xhat=d["xhat"], uhat=d["uhat"],
                               zx=d["zx"], lx=d["lx"], zu=d["zu"], lu=d["lu"], solve_mode=mode, active=dact, rec=rec)
-    hk.riccati_gain_ff(g, ff, "f64")
+    hk.riccati_gain_ff(g, ff, dtype)
     torch.cuda.synchronize()
     for name, ref, got in (("K", K, dK), ("k", k, dk_)):
         got = got.cpu().numpy()
@@ -548,11 +580,11 @@ def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x):
         bad = np.argwhere(~np.isfinite(got))
         assert bad.size == 0, f"{name}: HIP not finite at {bad[:6].tolist()} ({len(bad)} entries)"
         err = np.max(np.abs(ref - got)) / max(1.0, np.max(np.abs(ref)))
-        assert err < 1e-10, f"{name}: rel err {err:.3e}"
+        assert err < tol, f"{name}: rel err {err:.3e}"
         assert np.array_equal(got[[1, B - 2]], (K0 if name == "K" else k0)[[1, B - 2]]), f"{name}: inactive trajectory touched"
     assert np.array_equal(dst.cpu().numpy(), st)
     # a second feed-forward pass on the same records (the ADMM state moved) agrees with the oracle's as well
-    zu2 = zu + 0.2 * rng.standard_normal(zu.shape)
+    zu2 = zu + 0.2 * rn(*zu.shape)
     k2 = k.copy()
     okern.riccati_ff(A, Bm, c0x, c0u, K, Quu, fac, Qux, k2, Rr=np.tile(Rr, (N, 1, 1)), xhat=xhat, uhat=uhat, zu=zu2, lu=lu,
                      solve_mode=mode, active=active, **kwx)
@@ -561,7 +593,7 @@ def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x):
                   zx=d["zx"], lx=d["lx"], zu=d["zu2"], lu=d["lu"], solve_mode=mode, active=dact, rec=rec)
     torch.cuda.synchronize()
     err = np.max(np.abs(k2 - dk_.cpu().numpy())) / max(1.0, np.max(np.abs(k2)))
-    assert err < 1e-10, f"second pass k: rel err {err:.3e}"
+    assert err < tol, f"second pass k: rel err {err:.3e}"
 
 
 @pytest.mark.parametrize("nb_dim,nb_deriv", [(1, 3), (2, 3), (2, 1), (3, 1)])
@@ -609,6 +641,19 @@ def test_short_horizons_through_the_record_path(dual, N):
     from helpers import outer_iteration_on_device
     err = outer_iteration_on_device(cfg, range(9), hip_kernels(), dk.oracle, 7, 3, cfg["rho_u"], cfg["relax"])
     assert err < 1e-10, f"N={N}: {err:.2e}"
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 1e-4)])
+@pytest.mark.parametrize("B,J,L", [(33, 3, 20), (8, 5, 7)])
+def test_outer_driver_both_precisions(oracle, B, J, L, dtype, tol):
+    """isls_ilqr_admm_outer_f64 / _f32 as bench.py runs it (gain pass with the first feed-forward pass inside, record
+    feed-forward passes on time-invariant weights, ADMM updates fused into the rollout) over two outer iterations against the
+    oracle's own driver of the same precision: K, k, the x-step, z, lambda, residuals, the accepted nominal and its cost."""
+    from dual import hip_kernels
+    from helpers import outer_iteration_on_device
+    cfg = P.config2(batch=B, N=100, seed=7)
+    err = outer_iteration_on_device(cfg, range(B), hip_kernels(), oracle, L, J, cfg["rho_u"], cfg["relax"], dtype=dtype, outer_iters=2)
+    assert err < tol, f"{dtype}: {err:.2e}"
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

@@ -252,6 +252,31 @@ def test_isls_admm_robust_control_bounds(oracle, golden):
 
 
 @pytest.mark.gpu
+def test_isls_admm_host_get_AB_with_recorded_iteration(golden):
+    """The reference's calling convention -- `get_AB` a host callable, the forward model a device descriptor, the projection a
+    device set -- keeps the recorded ADMM iteration (HIP graph) in use across outer iterations: the linearisation a callback
+    returns per outer iteration must land in the buffers the recording points at.  Same results as the built-in linearisation
+    (`get_AB=None`) up to the rounding of the host / device Jacobians (CON_TOL; stale addresses give O(1) differences)."""
+    g = golden("g9_isls_admm.npz")
+    cfg, cs = arm_cfg(), control_sets(g)
+    kw = dict(max_line_search=30, k_max=3, project_u=cs, rho_u=1.0, max_admm_iter=4, threshold=0.0)
+    s0 = make_arm(cfg, [0, 1])
+    du0, phi0 = s0.isls_admm(3, None, **kw)
+    s1 = make_arm(cfg, [0, 1])
+    mdl = s1.forward_model
+    calls = []
+
+    def get_AB(x, u):
+        calls.append(1)
+        return mdl.get_AB(x, u)
+    du1, phi1 = s1.isls_admm(3, get_AB, **kw)
+    assert len(calls) == 2 * 3                                               # one callback per problem and outer iteration
+    assert rel(du1, du0) < CON_TOL and rel(phi1, phi0) < CON_TOL
+    assert rel(s1.x_nom, s0.x_nom) < CON_TOL and rel(s1.u_nom, s0.u_nom) < CON_TOL
+    assert rel(np.array(s1.cost_log), np.array(s0.cost_log)) < CON_TOL
+
+
+@pytest.mark.gpu
 def test_isls_admm_callable_projection_equals_device_sets(oracle, golden):
     """project_u given as the notebook's numpy closure (host round trip) runs the same iteration as the ConvexSets route."""
     g = golden("g9_isls_admm.npz")
