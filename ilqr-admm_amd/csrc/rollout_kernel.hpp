@@ -17,10 +17,15 @@
 //             a general tail (clamped refills, padded dead steps).
 //             Every S steps each candidate drops its state into an LDS checkpoint.
 //   ARG-MIN : first minimum over the slot's candidates (numpy NaN semantics, optional NaN rule/accept test).
-//   WINNER  : the reference returns x_noms[ind]; re-running the winner sequentially would cost another N
-//             dependent steps, so the horizon is cut into NSEG segments of S steps and lane c < NSEG replays
-//             segment c from the winner's checkpoint, fetching its own operands one iteration ahead.  The
-//             trajectory is collected in LDS (over the dead records and checkpoints), leaves in one coalesced
+//   WINNER  : the reference returns x_noms[ind].  The search RECORDS the controls of one candidate per trajectory -- the winner
+//             of the previous line search of that trajectory (isls_rollout_args.best as it stands at launch) -- in the slot's
+//             LDS, step by step.  When that candidate wins again (the rule in the ADMM iterations of an outer iteration, where
+//             the full step keeps winning) the winner's u_t are already on chip: the fused ADMM update sweeps them at once, and
+//             x_t, where somebody will read it, follows from the candidates' checkpoints (every S steps) by NSEG lanes
+//             stepping the model through their segments -- no operand of the search is fetched a second time.
+//             Otherwise the winner is REPLAYED: the horizon is cut into NSEG segments of S steps and the lanes of segment sg
+//             re-run steps [sg S, (sg+1) S) of candidate `ind` from its checkpoint, fetching K_t, k_t, xhat_t, uhat_t again.
+//             Either way the trajectory is collected in LDS (x over the dead records and checkpoints), leaves in one coalesced
 //             sweep, and the element-wise ADMM update of the outer driver rides on it.
 #pragma once
 // Ablation switches (wrong results by design; tools/ab_build.sh + tools/kbench.py): -DISLS_RO_EXP_NOREPLAY
@@ -39,6 +44,8 @@ struct RoP {
     int B, N, L, flags, nseg, seg_len;
     int seg_lanes;                 // lanes per replay segment: 1, or NU (one control row per lane)
     int stage_on;                  // winner trajectory collected in LDS and written out in one sweep (it fits the slot)
+    int u_off;                     // element offset of the winner's u rows [N][NU] in the slot's region (behind x [N][NX] and, with
+                                   // the recording on, behind the search's records and checkpoints: they are written DURING the search)
     const T *par;
     int64_t par_sb;
     const T *K, *k, *xhat, *uhat, *x0, *alphas;
@@ -197,17 +204,22 @@ struct RoLayout {
     static constexpr int BPAIRS = npair(NX) + npair(NU);        // the two groups with a second operand (z - lambda)
     static_assert(BPAIRS <= 8, "the z - lambda groups must fit the first load slot of the narrowest slot width");
     // slot (elements): aug[GL] | plain[GL] | model | region
-    //   region during the search: 2 records | checkpoints [L+1][nseg][NX] (row L: dump for idle lanes)
-    //   region after it         : the winner's trajectory x [N][NX] | u [N][NU] (the "stage"), written out in one sweep
-    static constexpr int MDL = NX * (NX + NU);                 // model words of the slot ([A B] of an LTI model)
+    //   region during the search: 2 records | checkpoints [L+1][nseg][NX] (row L: dump for idle lanes) | ... | u [N][NU]
+    //   region after it         : the winner's trajectory x [N][NX] | ... | u [N][NU] (the "stage"), written out in one sweep
+    //   with the stage on, the u rows sit behind BOTH (u_off): the search records the predicted winner's controls there
+    __host__ __device__ static constexpr int mdl_elems(int mdlw) { return mdlw + (mdlw & 1); }   // model words of the slot ([A B] of an LTI model), even
+    __host__ __device__ static constexpr int search_elems(int L, int nseg) { return 2 * RECP + (L + 1) * nseg * NX + 1; }
+    __host__ __device__ static constexpr int u_off(int L, int nseg, int N)
+    {
+        return search_elems(L, nseg) > N * NX ? search_elems(L, nseg) : N * NX;
+    }
     __host__ __device__ static constexpr int region_elems(int L, int nseg, int N, bool stage_on)
     {
-        const int srch = 2 * RECP + (L + 1) * nseg * NX + 1, stage = stage_on ? N * (NX + NU) + 1 : 0;
-        return srch > stage ? srch : stage;
+        return stage_on ? u_off(L, nseg, N) + N * NU + 1 : search_elems(L, nseg);
     }
-    __host__ __device__ static constexpr int slot_elems(int L, int GL, int nseg, int N, bool stage_on)
+    __host__ __device__ static constexpr int slot_elems(int L, int GL, int nseg, int N, bool stage_on, int mdlw)
     {
-        const int e = 2 * GL + MDL + region_elems(L, nseg, N, stage_on);
+        const int e = 2 * GL + mdl_elems(mdlw) + region_elems(L, nseg, N, stage_on);
         return W == 2 ? e + (e & 1) : e;                       // even: the records of every slot stay 16-byte aligned
     }
     // pairs the load plan really has for a launch (the launcher picks the kernel's slot count JM from it)
@@ -340,7 +352,7 @@ __device__ __forceinline__ void ro_wfetch(RoWOp<T, NX, RPL> &o, const T *wK, con
 template <typename T, int NX, int NU, int MODEL, int RL, int WD, bool STAGE>
 __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, int c, int ind, bool valid, bool accept, bool stage_on,
                                           int N, int NSEG, int S, int64_t bN, T alpha_w, const T *pK, const T *pk, const T *pxh,
-                                          const T *puh, const T *ck, T *stage, T *ubuf, int gl, T *x_out, T *u_out)
+                                          const T *puh, const T *ck, T *stage, int uoff, T *ubuf, int gl, T *x_out, T *u_out)
 {
     constexpr int RPL = NU / RL;                               // control rows per lane
     static_assert(RPL * RL == NU, "lanes per segment must divide the control dimension");
@@ -416,7 +428,7 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
 #endif
                     const bool own = in && c < nl;
                     const bool xown = own && (RL == 1 || r0 == 0);     // the first lane of a segment stores x_t, every lane its rows of u_t
-                    T *sx = stage + (xown ? t * NX : sdump), *su = stage + (own ? N * NX + t * NU + r0 : sdump);
+                    T *sx = stage + (xown ? t * NX : sdump), *su = stage + (own ? uoff + t * NU + r0 : sdump);
                     const int sstx = xown ? 1 : 0, sstu = own ? 1 : 0;
 #pragma unroll
                     for (int j = 0; j < NX; ++j) sx[j * sstx] = xw[j];
@@ -439,6 +451,34 @@ __device__ __forceinline__ void ro_replay(const Model<T, NX, NU, MODEL> &model, 
     }
 }
 
+// x_t of a recorded winner (its u_t sit in the stage's u rows): lane sg < NSEG steps the model through segment sg from the
+// winner's checkpoint with the recorded controls -- LDS only, no operand of the search is fetched again.
+template <typename T, int NX, int NU, int MODEL>
+__device__ __forceinline__ void ro_xreplay(const Model<T, NX, NU, MODEL> &model, int c, int ind, int N, int NSEG, int S, const T *ck,
+                                           T *stage, const T *ustage)
+{
+    const int sg = c < NSEG ? c : 0;
+    const int t0 = sg * S, t1 = (t0 + S < N) ? t0 + S : N;
+    T xw[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) xw[j] = ck[(ind * NSEG + sg) * NX + j];
+    slot_sync();                                               // every checkpoint is read before x_t overwrites it
+    const bool own = c < NSEG;
+    for (int t = t0; t < t0 + S; ++t) {
+        const int tt = t < N ? t : N - 1;
+        T u[NU], xn[NX];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) u[r] = ustage[tt * NU + r];
+        if (own && t < t1) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) stage[t * NX + j] = xw[j];
+        }
+        model.step(xw, u, xn);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xw[j] = xn[j];
+    }
+}
+
 #define ISLS_RO_LD(ptr) ro_load<T, W>(ptr)
 template <typename T, int NX, int NU, int MODEL, int JM, int OCC>
 __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
@@ -455,7 +495,8 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
     const int L = p.L, N = p.N, NSEG = p.nseg, S = p.seg_len;
     const int GL = L > 8 ? L : 8, TPW = kWave / GL;
     const bool stage_on = p.stage_on != 0;
-    const int SLOT = LY::slot_elems(L, GL, NSEG, N, stage_on);
+    constexpr int MDLW = Model<T, NX, NU, MODEL>::LDS_WORDS;
+    const int SLOT = LY::slot_elems(L, GL, NSEG, N, stage_on, MDLW);
     const int lane = threadIdx.x;
     // lanes beyond TPW*GL join the last slot as extra idle candidate lanes (c >= GL): they help nobody and
     // write only dump words, but need no slot of their own
@@ -468,9 +509,11 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
     const int64_t bN = (int64_t)bb * N;
     T *slot = lds + s * SLOT;
     T *c_aug = slot, *c_pln = c_aug + GL, *mdl = c_pln + GL;
-    T *recs = static_cast<T *>(__builtin_assume_aligned(mdl + LY::MDL, W == 2 ? 2 * sizeof(T) : sizeof(T)));
+    T *recs = static_cast<T *>(__builtin_assume_aligned(mdl + LY::mdl_elems(MDLW), W == 2 ? 2 * sizeof(T) : sizeof(T)));
     T *ck = recs + 2 * RECP;
-    T *stage = recs;                                           // winner trajectory, over the dead records + checkpoints
+    T *stage = recs;                                           // winner trajectory: x over the dead records + checkpoints,
+    const int uoff = p.u_off;                                  // u behind them (recorded during the search)
+    T *ustage = stage + uoff;
     const bool absolute = (p.flags & ISLS_RO_ABSOLUTE) != 0;
     const bool has_xh = !absolute && p.xhat != nullptr, has_uh = !absolute && p.uhat != nullptr;
     const bool has_wq = p.wq.p != nullptr, has_wr = p.wr.p != nullptr;
@@ -550,6 +593,18 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
         qm3 = __ballot(lane + 192 < N && qnzp[lane + 192 < N ? lane + 192 : 0] != 0);
     }
     int next_q = use_mask ? ro_next_bit(qm0, qm1, qm2, qm3, 0) : 0;   // next step with a non-zero Q_t (256: none left)
+    // ---- recording: the candidate that won this trajectory's previous line search drops its u_t into the stage's u rows as
+    // the search goes; every other lane writes the same values to a dump word of its own (the slot's cost words, unused until
+    // the arg-min): the stores are unconditional
+    int pred = 0;
+    if (stage_on && p.best) {
+        pred = p.best[bb];
+        pred = pred < 0 ? 0 : (pred < L ? pred : L - 1);
+    }
+    const bool is_pred = stage_on && c == pred;
+    T *const udump = c_aug + c;                                // c < 2 GL: extra idle lanes are fewer than a slot's lanes
+    T *urw = is_pred ? ustage : udump;                         // running: u_t of the step the search is at
+    const int ust = is_pred ? 1 : 0, uadv = is_pred ? NU : 0;
     // ================================ SEARCH ==========================================================
     const T alpha = absolute ? T(1) : p.alphas[c < L ? c : 0];
     T x[NX];
@@ -631,6 +686,12 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
                 _Pragma("unroll") for (int j = 0; j < NX; ++j) acc += (x[j] - rxh[j]) * rK[r * NX + j];                     \
                 u[r] = (acc + alpha * rk[r]) + ruh[r];                                                                      \
             }                                                                                                               \
+        }                                                                                                                   \
+        {                                                     /* the predicted winner records u_t (dead steps: dump word) */ \
+            T *uw = (!TAILF || live) ? urw : udump;                                                                         \
+            const int us_ = (!TAILF || live) ? ust : 0;                                                                     \
+            _Pragma("unroll") for (int r = 0; r < NU; ++r) uw[r * us_] = u[r];                                              \
+            urw += uadv;                                                                                                    \
         }                                                                                                                   \
         T cst1 = cst, cu1 = cu, ag1 = ag;                                                                                   \
         bool nz = use_mask ? t == next_q : live;              /* (x-z)'Q(x-z), skipped where Q_t == 0 (uniform test) */     \
@@ -753,27 +814,42 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
     const unsigned long long targmin_ = __builtin_readcyclecounter();
 #endif
     // ================================ WINNER ==========================================================
-    // the lanes of segment sg replay steps [sg*S, min((sg+1)*S, N)) of candidate `ind` from its checkpoint, fetching their
-    // operands (K_t, k_t, xhat_t, uhat_t) themselves several iterations ahead.  The loop body has no exec-mask branch (steps
-    // past the end of the last segment compute on clamped operands and write the dump word), so the loads of the next
-    // iterations stay in flight behind the current one.  x_t, u_t go to the stage in LDS (or straight to HBM when the stage
-    // does not fit the slot).
+    // Recorded winner (every trajectory of the wavefront won by the candidate that recorded its controls): u_t is in the
+    // stage already; x_t is produced on demand by ro_xreplay below.  Otherwise the whole wavefront replays: the lanes of
+    // segment sg re-run steps [sg*S, min((sg+1)*S, N)) of candidate `ind` from its checkpoint, fetching their operands (K_t,
+    // k_t, xhat_t, uhat_t) themselves several iterations ahead.  That loop has no exec-mask branch (steps past the end of
+    // the last segment compute on clamped operands and write the dump word), so the loads of the next iterations stay in
+    // flight behind the current one.  x_t, u_t go to the stage in LDS (or straight to HBM when the stage does not fit the slot;
+    // a trajectory that hit its prediction gets the same values again).
+#ifdef ISLS_RO_EXP_ALLMISS
+    const bool any_miss = true;                                // A/B build: the winner is always replayed
+#else
+    const bool any_miss = !stage_on || __ballot(valid && ind != pred) != 0ull;   // uniform
+#endif
+    // x_t is needed now unless the fused ADMM update only sweeps u and further ADMM iterations follow (then only a trajectory
+    // that stops in this update is written out: decided behind the sweep)
+    const bool x_early = !p.fa_on || p.fa_last || p.fa_zx != nullptr;   // uniform
+    bool x_ready = true;
 #ifndef ISLS_RO_EXP_NOREPLAY
-    {
+    if (any_miss) {
         const T alpha_w = absolute ? T(1) : p.alphas[ind];
         const T *pxh = has_xh ? p.xhat : nullptr, *puh = has_uh ? p.uhat : nullptr;
         if (p.seg_lanes > 1 && stage_on)
             ro_replay<T, NX, NU, MODEL, NU, 4, true>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                                     stage, c_aug, GL, p.x_out, p.u_out);
+                                                     stage, uoff, c_aug, GL, p.x_out, p.u_out);
         else if (p.seg_lanes > 1)
             ro_replay<T, NX, NU, MODEL, NU, 4, false>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                                      stage, c_aug, GL, p.x_out, p.u_out);
+                                                      stage, uoff, c_aug, GL, p.x_out, p.u_out);
         else if (stage_on)
             ro_replay<T, NX, NU, MODEL, 1, 2, true>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                                    stage, c_aug, GL, p.x_out, p.u_out);
+                                                    stage, uoff, c_aug, GL, p.x_out, p.u_out);
         else
             ro_replay<T, NX, NU, MODEL, 1, 2, false>(model, c, ind, valid, accept, stage_on, N, NSEG, S, bN, alpha_w, p.K, p.k, pxh, puh, ck,
-                                                     stage, c_aug, GL, p.x_out, p.u_out);
+                                                     stage, uoff, c_aug, GL, p.x_out, p.u_out);
+    } else if (x_early) {
+        ro_xreplay<T, NX, NU, MODEL>(model, c, ind, N, NSEG, S, ck, stage, ustage);
+    } else {
+        x_ready = false;
     }
 #endif
 #ifdef ISLS_DIAG
@@ -789,7 +865,7 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
         T *xo = p.x_out + bN * NX, *uo = p.u_out + bN * NU;                                  \
         if (accept) {                                                                        \
             for (int e = c; e < N * NX; e += GL) xo[e] = stage[e];                           \
-            for (int e = c; e < N * NU; e += GL) uo[e] = stage[N * NX + e];                  \
+            for (int e = c; e < N * NU; e += GL) uo[e] = ustage[e];                          \
         } else {                                                                             \
             for (int e = c; e < N * NX; e += GL) xo[e] = p.xhat[bN * NX + e];                \
             for (int e = c; e < N * NU; e += GL) uo[e] = p.uhat[bN * NU + e];                \
@@ -817,7 +893,7 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
             T *zz = isx ? fa_zx : fa_zu, *ll = isx ? fa_lx : fa_lu;
             if (zz == nullptr) return;                         // uniform
             const int cnt = N * d, proj = isx ? fa_proj_x : fa_proj_u;
-            const T *src = isx ? stage : stage + N * NX;
+            const T *src = isx ? stage : ustage;
             const T *lo_p = (isx ? fa_xlo : fa_ulo).at(b, 0), *hi_p = (isx ? fa_xhi : fa_uhi).at(b, 0);
             const int lo_st = (int)(isx ? fa_xlo : fa_ulo).st, hi_st = (int)(isx ? fa_xhi : fa_uhi).st;
             T p2 = T(0), d2 = T(0);
@@ -893,6 +969,10 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
             if (p.fa_iters) p.fa_iters[b] += 1;
         }
         if (!fa_stop) write_out = false;                       // the trajectory goes on: its next x-step overwrites x_out / u_out
+        if (!x_ready && __ballot(write_out) != 0ull) {         // a recorded winner stops here: its x_t after all (uniform)
+            ro_xreplay<T, NX, NU, MODEL>(model, c, ind, N, NSEG, S, ck, stage, ustage);
+            slot_sync();
+        }
         ISLS_RO_WRITE_OUT()
     }
 #undef ISLS_RO_WRITE_OUT
@@ -923,7 +1003,8 @@ int launch_rollout_family_impl(RoP<T> &p, const isls_rollout_args &a, hipStream_
     // each, ro_replay).  An iteration of the one-lane form is a scattered gather (~4x the time of the row form's), so the
     // row form wins unless it gets far fewer segments
     bool stage_on = true;
-    auto smem_bytes = [&](int ns) { return (size_t)TPW * LY::slot_elems(a.L, GL, ns, a.N, stage_on) * sizeof(T); };
+    constexpr int MDLW = Model<T, NX, NU, MODEL>::LDS_WORDS;
+    auto smem_bytes = [&](int ns) { return (size_t)TPW * LY::slot_elems(a.L, GL, ns, a.N, stage_on, MDLW) * sizeof(T); };
     // the winner's trajectory is collected in LDS when that keeps the workgroup under 28 KB (>= 5 per CU); longer horizons
     // store it step by step
     if (smem_bytes(1) > 28 * 1024) stage_on = false;
@@ -941,6 +1022,7 @@ int launch_rollout_family_impl(RoP<T> &p, const isls_rollout_args &a, hipStream_
     p.seg_len = (a.N + nseg - 1) / nseg;
     p.nseg = (a.N + p.seg_len - 1) / p.seg_len;                // drop empty trailing segments
     p.stage_on = stage_on ? 1 : 0;
+    p.u_off = LY::u_off(a.L, p.nseg, a.N);
     if (stage_ok) *stage_ok = stage_on;
     if (!stage_on) p.fa_on = 0;                                 // the fused update reads x, u from the stage: the caller runs it as its own launch
     (void)want_fused;
