@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--L", type=int, default=20)
     ap.add_argument("--lti", action="store_true", help="share A,B over batch and time (stride-0 views)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-launches", action="store_true",
+                    help="A/B: accept, ADMM restart, linearisation and expansion as four launches instead of isls_outer_advance")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories in the CPU-baseline sample (0: auto)")
     ap.add_argument("--config5", action="store_true", help="secondary workload: SLS-ADMM with chance constraints (B=8192, N=50)")
     ap.add_argument("--config5-dim", type=int, default=1, help="double integrator dimension of the config-5 workload (1 or 3)")
@@ -180,7 +182,8 @@ def main():
     if args.lti:
         eng.A = torch.as_tensor(cfg["A"], device=dev).reshape(1, 1, n, n)
         eng.Bm = torch.as_tensor(cfg["B"], device=dev).reshape(1, 1, n, m)
-    eng.build_outer(L, J, tol_abs=0.0, tol_rel=0.0)          # tolerances 0: no early exit, fixed work
+    # tolerances 0: no early exit, fixed work.  begin_done: every step ends with eng.advance(), which makes the ADMM restart
+    eng.build_outer(L, J, tol_abs=0.0, tol_rel=0.0, begin_done=not args.separate_launches)
     # convergence table of every outer iteration: this shard's row + ONE asynchronous all-reduce (RCCL's own stream); the
     # compute stream never waits for it, the host reads the table an iteration late (isls/shard.py::TableExchange)
     xch = TableExchange(world, rank, torch.float64, dev)
@@ -189,13 +192,24 @@ def main():
         xch.post(lambda table, r: eng.reduce(table=table, rank=r))
 
     def step():
-        if not args.lti:
-            eng.linearize()                                   # A_t,B_t of every trajectory rewritten in HBM
-        eng.expand()                                          # Cxx,Cuu,c0x,c0u about the nominal
-        eng.run_outer()                                       # gain + J x (ff, rollout, update), one C call
-        eng.accept_x_step()                                   # nominal <- x-step, cost log (no stop rule)
+        # one outer iteration = gain + J x (ff, rollout, update) [one C call], then ONE launch for what sits between two
+        # x-step solves: nominal <- x-step and cost log (no stop rule), ADMM restart, A_t,B_t of every trajectory rewritten
+        # in HBM (--lti: shared, not rewritten), c0x,c0u about the new nominal -- every step runs each stage once; the
+        # linearisation / expansion the first step consumes is made below, before the warm-up
+        eng.run_outer()
+        if args.separate_launches:
+            eng.accept_x_step()
+            if not args.lti:
+                eng.linearize()
+            eng.expand()
+        else:
+            eng.advance(linearize=not args.lti)
         exchange()                                            # this shard's row of the [W,5] table (one launch) + the one collective
 
+    if not args.lti:
+        eng.linearize()
+    eng.expand()                                              # also writes the batch-shared Cxx, Cuu tables once
+    eng.begin_outer()
     lib = library()
     for _ in range(args.warmup):
         step()
@@ -230,12 +244,15 @@ def main():
     if not args.lti:
         eng.A = torch.as_tensor(cfg["A"], device=dev).reshape(1, 1, n, n)
         eng.Bm = torch.as_tensor(cfg["B"], device=dev).reshape(1, 1, n, m)
-        eng.build_outer(L, J, tol_abs=0.0, tol_rel=0.0)
+        eng.build_outer(L, J, tol_abs=0.0, tol_rel=0.0, begin_done=not args.separate_launches)
 
         def step_lti():
-            eng.expand()
             eng.run_outer()
-            eng.accept_x_step()
+            if args.separate_launches:
+                eng.accept_x_step()
+                eng.expand()
+            else:
+                eng.advance(linearize=False)
             exchange()
 
         step_lti()

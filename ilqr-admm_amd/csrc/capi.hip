@@ -47,8 +47,10 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
 {
     const isls_admm_args &ad = a.admm;
     Timing *const tmg = static_cast<Timing *>(a.timing);
-    int rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, ad.iters, s);
-    if (rc != ISLS_OK) return rc;
+    int rc = ISLS_OK;
+    if (!a.begin_done &&
+        (rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, ad.iters, s)) != ISLS_OK)
+        return rc;
     bool ff_done = false;                                      // the gain pass ran the first feed-forward pass as well
     if (!a.skip_gain) {
         {
@@ -213,6 +215,14 @@ ISLS_API int isls_accept_step_f32(const isls_accept_args *a, void *stream)
 {
     if (a && a->B == 0) return ISLS_OK;
     return a ? launch_accept<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_outer_advance_f64(const isls_advance_args *a, void *stream)
+{
+    return a ? launch_advance<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_outer_advance_f32(const isls_advance_args *a, void *stream)
+{
+    return a ? launch_advance<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
 ISLS_API int isls_reduce_convergence_f64(int32_t B, const void *cost, const void *res, const int32_t *active,
                                          const int32_t *status, void *out5, void *stream)

@@ -216,6 +216,7 @@ template <typename T> int launch_columns_admm(const isls_columns_admm_args &a, h
 template <typename T> int launch_expand(const isls_expand_args &a, hipStream_t s);
 template <typename T> int launch_linearize(const isls_linearize_args &a, hipStream_t s);
 template <typename T> int launch_accept(const isls_accept_args &a, hipStream_t s);
+template <typename T> int launch_advance(const isls_advance_args &a, hipStream_t s);
 template <typename T> int launch_reduce(int32_t B, const void *cost, const void *res, const int32_t *active,
                                         const int32_t *status, void *out5, hipStream_t s, int row = -1, int rows = 0);
 template <typename T> int launch_outer_begin(int32_t B, int32_t N, int32_t n, int32_t m, int32_t *admm_active,

@@ -26,10 +26,8 @@ struct ExpP {
 };
 
 template <typename T>
-__global__ __launch_bounds__(64) void expand_kernel(ExpP<T> p)
+__device__ __forceinline__ void expand_body(const ExpP<T> &p, int b)
 {
-    const int b = blockIdx.x;
-    if (p.active && p.active[b] == 0) return;
     const int N = p.N, n = p.n, m = p.m, lane = threadIdx.x;
     const T *Qtab = p.Qtab + (int64_t)b * p.Qtab_sb, *ztab = p.ztab + (int64_t)b * p.ztab_sb;
     const int64_t bN = (int64_t)b * N;
@@ -116,13 +114,19 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpP<T> p)
 }
 
 template <typename T>
-int launch_expand(const isls_expand_args &a, hipStream_t s)
+__global__ __launch_bounds__(64) void expand_kernel(ExpP<T> p)
+{
+    const int b = blockIdx.x;
+    if (p.active && p.active[b] == 0) return;
+    expand_body(p, b);
+}
+
+template <typename T>
+static int expand_params(const isls_expand_args &a, ExpP<T> &p)
 {
     if (a.B < 0 || a.N < 1 || a.n < 1 || a.m < 1 || !a.c0x || !a.c0u) return ISLS_ERR_ARG;
     if (a.cost_model == ISLS_COST_VIA && (!a.Qtab || !a.ztab || !a.seq)) return ISLS_ERR_ARG;
     if (a.cost_model != ISLS_COST_VIA && (a.cost_model != ISLS_COST_PHUBER || !a.cost_par)) return ISLS_ERR_UNSUPPORTED;
-    if (a.B == 0) return ISLS_OK;
-    ExpP<T> p;
     p.B = a.B; p.N = a.N; p.n = a.n; p.m = a.m;
     p.Qtab = (const T *)a.Qtab; p.ztab = (const T *)a.ztab; p.Qtab_sb = a.Qtab_sb; p.ztab_sb = a.ztab_sb;
     p.seq = a.seq; p.u_std = (T)a.u_std;
@@ -131,6 +135,16 @@ int launch_expand(const isls_expand_args &a, hipStream_t s)
     p.Cxx = (T *)a.Cxx; p.Cuu = (T *)a.Cuu; p.c0x = (T *)a.c0x; p.c0u = (T *)a.c0u; p.cost = (T *)a.cost;
     p.active = a.active;
     p.cost_model = a.cost_model; p.cpar = (const T *)a.cost_par; p.qnz = a.q_nonzero;
+    return ISLS_OK;
+}
+
+template <typename T>
+int launch_expand(const isls_expand_args &a, hipStream_t s)
+{
+    ExpP<T> p;
+    const int rc = expand_params<T>(a, p);
+    if (rc != ISLS_OK) return rc;
+    if (a.B == 0) return ISLS_OK;
     hipLaunchKernelGGL((expand_kernel<T>), dim3(a.B), dim3(64), 0, s, p);
     return check_launch();
 }
@@ -149,12 +163,8 @@ struct LinP {
 };
 
 template <typename T>
-__global__ __launch_bounds__(64) void linearize_kernel(LinP<T> p)
+__device__ __forceinline__ void linearize_body(const LinP<T> &p, int b, T *tab)   // tab: [N][8] per-step trig terms (LDS)
 {
-    extern __shared__ __align__(16) unsigned char lin_smem[];
-    T *tab = reinterpret_cast<T *>(lin_smem);                 // [N][8] per-step trig terms
-    const int b = blockIdx.x;
-    if (p.active && p.active[b] == 0) return;
     const int N = p.N, n = p.n, m = p.m, lane = threadIdx.x;
     const T *par = p.par + (int64_t)b * p.par_sb;
     const int64_t bN = (int64_t)b * N;
@@ -302,7 +312,16 @@ __global__ __launch_bounds__(64) void linearize_kernel(LinP<T> p)
 }
 
 template <typename T>
-int launch_linearize(const isls_linearize_args &a, hipStream_t s)
+__global__ __launch_bounds__(64) void linearize_kernel(LinP<T> p)
+{
+    extern __shared__ __align__(16) unsigned char lin_smem[];
+    const int b = blockIdx.x;
+    if (p.active && p.active[b] == 0) return;
+    linearize_body(p, b, reinterpret_cast<T *>(lin_smem));
+}
+
+template <typename T>
+static int linearize_params(const isls_linearize_args &a, LinP<T> &p, size_t *tab_words)
 {
     if (a.B < 0 || a.N < 1 || !a.model_par || !a.A || !a.Bm) return ISLS_ERR_ARG;
     if (a.model != ISLS_MODEL_LTI && a.model != ISLS_MODEL_DI && (!a.xhat || !a.uhat)) return ISLS_ERR_ARG;
@@ -312,12 +331,21 @@ int launch_linearize(const isls_linearize_args &a, hipStream_t s)
     if (a.model == ISLS_MODEL_TASSA && !(a.n == 4 && a.m == 2)) return ISLS_ERR_UNSUPPORTED;
     if (a.model < ISLS_MODEL_LTI || a.model > ISLS_MODEL_TASSA) return ISLS_ERR_UNSUPPORTED;
     if ((size_t)a.N * 8 * sizeof(T) > 60000) return ISLS_ERR_UNSUPPORTED;
-    if (a.B == 0) return ISLS_OK;
-    LinP<T> p;
     p.B = a.B; p.N = a.N; p.n = a.n; p.m = a.m; p.model = a.model;
     p.par = (const T *)a.model_par; p.par_sb = a.model_par_sb;
     p.xhat = (const T *)a.xhat; p.uhat = (const T *)a.uhat; p.A = (T *)a.A; p.Bm = (T *)a.Bm; p.active = a.active;
-    const size_t tab_words = (size_t)a.N * 8 > (size_t)2 * a.n * (a.n + a.m) ? (size_t)a.N * 8 : (size_t)2 * a.n * (a.n + a.m);
+    *tab_words = (size_t)a.N * 8 > (size_t)2 * a.n * (a.n + a.m) ? (size_t)a.N * 8 : (size_t)2 * a.n * (a.n + a.m);
+    return ISLS_OK;
+}
+
+template <typename T>
+int launch_linearize(const isls_linearize_args &a, hipStream_t s)
+{
+    LinP<T> p;
+    size_t tab_words = 0;
+    const int rc = linearize_params<T>(a, p, &tab_words);
+    if (rc != ISLS_OK) return rc;
+    if (a.B == 0) return ISLS_OK;
     hipLaunchKernelGGL((linearize_kernel<T>), dim3(a.B), dim3(64), tab_words * sizeof(T), s, p);
     return check_launch();
 }
@@ -326,17 +354,16 @@ template int launch_linearize<float>(const isls_linearize_args &, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // end of an outer iteration: nominal <- x-step, cost log tail, outer stop rules (isls/isls.py:488-499)
+// returns (lane 0 only) whether a stop rule fired
 template <typename T>
-__global__ __launch_bounds__(64) void accept_kernel(int N, int n, int m, const T *xx, const T *xu, const T *cost_new,
-                                                    T *xhat, T *uhat, T *cost, T *hist, int32_t *hist_len,
-                                                    T tol_cost, T tol_osc, int32_t *outer_active)
+__device__ __forceinline__ bool accept_body(int b, int N, int n, int m, const T *xx, const T *xu, const T *cost_new,
+                                            T *xhat, T *uhat, T *cost, T *hist, int32_t *hist_len,
+                                            T tol_cost, T tol_osc, int32_t *outer_active)
 {
-    const int b = blockIdx.x;
-    if (outer_active && outer_active[b] == 0) return;
     const int64_t ox = (int64_t)b * N * n, ou = (int64_t)b * N * m;
     for (int e = threadIdx.x; e < N * n; e += kWave) xhat[ox + e] = xx[ox + e];
     for (int e = threadIdx.x; e < N * m; e += kWave) uhat[ou + e] = xu[ou + e];
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0) return false;
     const T prev = cost[b], cur = cost_new[b];
     cost[b] = cur;
     bool stop = false;
@@ -358,6 +385,17 @@ __global__ __launch_bounds__(64) void accept_kernel(int N, int n, int m, const T
         }
     }
     if (stop && outer_active) outer_active[b] = 0;
+    return stop && outer_active != nullptr;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void accept_kernel(int N, int n, int m, const T *xx, const T *xu, const T *cost_new,
+                                                    T *xhat, T *uhat, T *cost, T *hist, int32_t *hist_len,
+                                                    T tol_cost, T tol_osc, int32_t *outer_active)
+{
+    const int b = blockIdx.x;
+    if (outer_active && outer_active[b] == 0) return;
+    accept_body(b, N, n, m, xx, xu, cost_new, xhat, uhat, cost, hist, hist_len, tol_cost, tol_osc, outer_active);
 }
 
 template <typename T>
@@ -446,18 +484,24 @@ template int launch_reduce<float>(int32_t, const void *, const void *, const int
 // start of an outer iteration: admm_active <- outer_active, lambda <- 0 (isls.py:414-415,482),
 // previous residual norms <- 1e6 (admm.py:25-26), for the trajectories still iterating.
 template <typename T>
-__global__ __launch_bounds__(64) void outer_begin_kernel(int N, int n, int m, int32_t *admm_active,
-                                                         const int32_t *outer_active, T *lx, T *lu, T *res_prev,
-                                                         int32_t *iters)
+__device__ __forceinline__ void outer_begin_body(int b, bool act, int N, int n, int m, int32_t *admm_active, T *lx, T *lu,
+                                                 T *res_prev, int32_t *iters)
 {
-    const int b = blockIdx.x;
-    const bool act = outer_active == nullptr || outer_active[b] != 0;
     if (threadIdx.x == 0 && admm_active) admm_active[b] = act ? 1 : 0;
     if (!act) return;
     if (threadIdx.x == 0 && iters) iters[b] = 0;
     if (lx) for (int e = threadIdx.x; e < N * n; e += kWave) lx[(int64_t)b * N * n + e] = T(0);
     if (lu) for (int e = threadIdx.x; e < N * m; e += kWave) lu[(int64_t)b * N * m + e] = T(0);
     if (res_prev && threadIdx.x < 2) res_prev[(int64_t)b * 2 + threadIdx.x] = T(1e6);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void outer_begin_kernel(int N, int n, int m, int32_t *admm_active,
+                                                         const int32_t *outer_active, T *lx, T *lu, T *res_prev,
+                                                         int32_t *iters)
+{
+    const int b = blockIdx.x;
+    outer_begin_body(b, outer_active == nullptr || outer_active[b] != 0, N, n, m, admm_active, lx, lu, res_prev, iters);
 }
 
 template <typename T>
@@ -471,5 +515,79 @@ int launch_outer_begin(int32_t B, int32_t N, int32_t n, int32_t m, int32_t *admm
 }
 template int launch_outer_begin<double>(int32_t, int32_t, int32_t, int32_t, int32_t *, const int32_t *, void *, void *, void *, int32_t *, hipStream_t);
 template int launch_outer_begin<float>(int32_t, int32_t, int32_t, int32_t, int32_t *, const int32_t *, void *, void *, void *, int32_t *, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// isls_outer_advance: the end of one outer iteration and the start of the next in ONE launch (one wavefront per trajectory):
+// accept (nominal <- x-step, cost log, stop rules) -> start of the next iteration (admm_active, lambda, residual history)
+// -> linearisation and cost expansion about the new nominal, for the trajectories still iterating.  The four stages were
+// four launches that each re-read what the previous one had just written; here the new nominal is read from the x-step
+// arrays (the same numbers; nothing this launch writes is read back by it) and the launch gaps are gone.
+template <typename T>
+struct AdvP {
+    int N, n, m;
+    const T *xx, *xu, *cost_new;
+    T *xhat, *uhat, *cost, *hist;
+    int32_t *hist_len;
+    T tol_cost, tol_osc;
+    int32_t *outer_active;
+    int32_t *admm_active, *iters;
+    T *lx, *lu, *res_prev;
+    int has_lin, has_exp;
+    LinP<T> lin;
+    ExpP<T> exp;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void advance_kernel(AdvP<T> p)
+{
+    extern __shared__ __align__(16) unsigned char adv_smem[];
+    const int b = blockIdx.x;
+    bool act = p.outer_active == nullptr || p.outer_active[b] != 0;
+    if (act) {
+        const bool stopped = accept_body(b, p.N, p.n, p.m, p.xx, p.xu, p.cost_new, p.xhat, p.uhat, p.cost, p.hist, p.hist_len,
+                                         p.tol_cost, p.tol_osc, p.outer_active);
+        act = __builtin_amdgcn_readfirstlane(stopped ? 1 : 0) == 0;       // lane 0 evaluated the stop rules
+    }
+    outer_begin_body(b, act, p.N, p.n, p.m, p.admm_active, p.lx, p.lu, p.res_prev, p.iters);
+    if (!act) return;
+    if (p.has_lin) linearize_body(p.lin, b, reinterpret_cast<T *>(adv_smem));
+    if (p.has_exp) expand_body(p.exp, b);
+}
+
+template <typename T>
+int launch_advance(const isls_advance_args &a, hipStream_t s)
+{
+    const isls_accept_args &ac = a.accept;
+    if (ac.B < 0 || ac.N < 1 || !ac.xx || !ac.xu || !ac.cost_new || !ac.xhat || !ac.uhat || !ac.cost) return ISLS_ERR_ARG;
+    if (ac.cost_hist && !ac.hist_len) return ISLS_ERR_ARG;
+    AdvP<T> p;
+    p.N = ac.N; p.n = ac.n; p.m = ac.m;
+    p.xx = (const T *)ac.xx; p.xu = (const T *)ac.xu; p.cost_new = (const T *)ac.cost_new;
+    p.xhat = (T *)ac.xhat; p.uhat = (T *)ac.uhat; p.cost = (T *)ac.cost; p.hist = (T *)ac.cost_hist; p.hist_len = ac.hist_len;
+    p.tol_cost = (T)ac.tol_cost; p.tol_osc = (T)ac.tol_osc; p.outer_active = ac.outer_active;
+    p.admm_active = a.admm_active; p.iters = a.iters; p.lx = (T *)a.lx; p.lu = (T *)a.lu; p.res_prev = (T *)a.res_prev;
+    size_t tab_words = 0;
+    p.has_lin = a.lin.A != nullptr;
+    p.has_exp = a.exp.c0x != nullptr;
+    int rc;
+    if (p.has_lin) {
+        if ((rc = linearize_params<T>(a.lin, p.lin, &tab_words)) != ISLS_OK) return rc;
+        if (a.lin.B != ac.B || a.lin.N != ac.N || a.lin.n != ac.n || a.lin.m != ac.m) return ISLS_ERR_ARG;
+        // the nominal this launch writes is not read back by it: the same numbers come from the x-step arrays
+        if (p.lin.xhat == p.xhat) p.lin.xhat = p.xx;
+        if (p.lin.uhat == p.uhat) p.lin.uhat = p.xu;
+    }
+    if (p.has_exp) {
+        if ((rc = expand_params<T>(a.exp, p.exp)) != ISLS_OK) return rc;
+        if (a.exp.B != ac.B || a.exp.N != ac.N || a.exp.n != ac.n || a.exp.m != ac.m) return ISLS_ERR_ARG;
+        if (p.exp.xhat == p.xhat) p.exp.xhat = p.xx;
+        if (p.exp.uhat == p.uhat) p.exp.uhat = p.xu;
+    }
+    if (ac.B == 0) return ISLS_OK;
+    hipLaunchKernelGGL((advance_kernel<T>), dim3(ac.B), dim3(64), tab_words * sizeof(T), s, p);
+    return check_launch();
+}
+template int launch_advance<double>(const isls_advance_args &, hipStream_t);
+template int launch_advance<float>(const isls_advance_args &, hipStream_t);
 
 }  // namespace isls

@@ -42,6 +42,7 @@ struct GainP {
     View<T> c0x, c0u, Qr, Rr;
     const T *xhat, *uhat, *zx, *lx, *zu, *lu;
     T *kff;
+    int rev;                       // 1: the grid walks the trajectory blocks from the last to the first
 };
 
 // 1/sqrt(a) by v_rsq + two coupled Newton steps (g -> sqrt(a), h -> 1/(2 sqrt(a))): 9 instructions against the ~30 of
@@ -122,9 +123,10 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     __shared__ __align__(16) T img[2 * IMG];
 
     const int lane = threadIdx.x;
+    const int bx = p.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;   // trajectory block of this wavefront
     const bool inslot = lane / G < TPW;
     const int s = inslot ? lane / G : TPW - 1, i = inslot ? lane - (lane / G) * G : G - 1;   // surplus lanes repeat the last lane
-    const int b = blockIdx.x * TPW + s;
+    const int b = bx * TPW + s;
     const bool valid = b < p.B && (p.active == nullptr || p.active[b] != 0);
     const unsigned long long vmask = __ballot(valid);
     if (vmask == 0ull) return;                                 // nothing to do for this wavefront
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         // repeat piece 0 of the first valid slot
         const int e = lane + kWave * j, in = e < TPW * KU;
         const int sl = in ? e / KU : ssh, pc = in ? e - (e / KU) * KU : 0;
-        const int bk = blockIdx.x * TPW + sl;
+        const int bk = bx * TPW + sl;
         const bool ok = bk < p.B && (p.active == nullptr || p.active[bk] != 0);
         kso[j] = sl * RW + RK + pc * (KPAIRS ? 2 : 1);
         kgo[j] = (int64_t)(ok ? bk : bsh) * N * (NU * NX) + pc * (KPAIRS ? 2 : 1);
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
     int fw[JP];                                                // image word of the lane's j-th record pair
 #pragma unroll
     for (int j = 0; j < JP; ++j) { const int pq = lane + kWave * j; fw[j] = 2 * (pq < NPAIR ? pq : NPAIR - 1); }
-    T *const recg = REC ? p.rec + (int64_t)blockIdx.x * N * (TPW * RW) : nullptr;   // the wavefront's records, step 0
+    T *const recg = REC ? p.rec + (int64_t)bx * N * (TPW * RW) : nullptr;   // the wavefront's records, step 0
 
     // The image of a step is read back into fl / fk behind its sync (c) and leaves for HBM during the NEXT step, one store
     // between two blocks of that step's arithmetic: a wavefront waits while a store's data drains (the CU moves ~7-16 B per
@@ -649,6 +651,8 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     p.K = (T *)a.K; p.Quu = (T *)a.Quu; p.fac = (T *)a.fac; p.Qux = (T *)a.Qux; p.rec = (T *)a.rec;
     p.status = a.status; p.active = a.active;
     p.xhat = p.uhat = p.zx = p.lx = p.zu = p.lu = nullptr; p.kff = nullptr;
+    static const int rev_mode = [] { const char *e = getenv("ISLS_GAIN_REV"); return e ? atoi(e) : 0; }();   // EXPERIMENT
+    p.rev = rev_mode ? 1 : 0;
     // the first feed-forward pass rides along when it would run on this pass's records with time-invariant Qr / Rr rows
     const bool with_ff = ff && gain_ff_dims(a.n, a.m) && a.rec && ff->rec == a.rec && ff->k && ff->B == a.B && ff->N == a.N && ff->n == a.n && ff->m == a.m &&
                          ff->solve_mode == a.solve_mode && ff->active == a.active && ff->c0x.p && ff->c0u.p &&

@@ -40,6 +40,7 @@ struct FfRecP {
     const T *rec;                  // [ceil(B/TPW)][N][TPW][RW]: the records of a wavefront's trajectories are contiguous per step
     T *k;
     const int32_t *active;
+    int rev;                       // 1: the grid walks the trajectory blocks from the last to the first (see launch_ff_record)
 };
 
 // FG: ring entries are refilled in groups of FG consecutive steps -- one burst of FG records (FG x 648 B at n=6, m=3) per
@@ -268,9 +269,10 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     typedef T V2 __attribute__((ext_vector_type(2)));
 
     const int lane = threadIdx.x;
+    const int bx = p.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;   // trajectory block of this wavefront
     const bool inslot = lane / G < TPW;
     const int s = inslot ? lane / G : TPW - 1, i = inslot ? lane - (lane / G) * G : G - 1;   // surplus lanes repeat the last lane
-    const int b = blockIdx.x * TPW + s;
+    const int b = bx * TPW + s;
     const bool valid = b < p.B && (p.active == nullptr || p.active[b] != 0);
     const unsigned long long vmask = __ballot(valid);
     if (vmask == 0ull) return;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     // A slot that shadows another trajectory still reads its own place in the run (whatever the gain pass left there) but
     // restages the shadowed slot's record below, so it computes exactly what that slot computes.
     constexpr int BW = TPW * RW, NP = BW / 2, JR = (NP + kWave - 1) / kWave;
-    const T *bR = p.rec + (int64_t)blockIdx.x * N * BW;
+    const T *bR = p.rec + (int64_t)bx * N * BW;
     uint32_t oR[JR];
     int dR[JR];
 #pragma unroll
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
         dR[j] = w < BW ? (w / RW) * SLOT + (w % RW) : TPW * SLOT + DUMP_OFF;
     }
     // where this lane READS its slot's record: its own slot, or the shadowed one
-    const int ssh = (bb - blockIdx.x * TPW);                   // slot of the trajectory the lane computes (== s when valid)
+    const int ssh = (bb - bx * TPW);                   // slot of the trajectory the lane computes (== s when valid)
     const T *rrec = lds + ssh * SLOT;
     // vectors: own component of c0, xhat/uhat, z, lambda (lanes without a regularised block load c0 again and drop it)
     const T *pc0 = xl ? p.c0x.at(bb, 0) + i : p.c0u.at(bb, 0) + iu;
@@ -511,6 +513,10 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
     p.seg_len = segmented ? a.seg.seg_len : (a.N > 1 ? a.N - 1 : 1);
     p.vseg = segmented ? (T *)a.seg.v : nullptr;
     const bool rowc = (!a.Qr.p || a.Qr.st == 0) && (!a.Rr.p || a.Rr.st == 0);
+    // EXPERIMENT (ISLS_FF_REV = 1: every pass walks the blocks backwards; 2: consecutive passes alternate)
+    static const int rev_mode = [] { const char *e = getenv("ISLS_FF_REV"); return e ? atoi(e) : 0; }();
+    static int rev_count = 0;
+    p.rev = rev_mode == 1 ? 1 : (rev_mode == 2 ? (rev_count++ & 1) : 0);
 #ifndef ISLS_FF2_SEQ_DEPTH
 #define ISLS_FF2_SEQ_DEPTH 3
 #endif

@@ -17,7 +17,7 @@ try:  # torch is plumbing (device memory, streams); the binding itself works on 
 except Exception:  # pragma: no cover
     torch = None
 
-ABI_VERSION = 104            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
+ABI_VERSION = 105            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
@@ -168,14 +168,19 @@ class ColumnsAdmmArgs(C.Structure):
 
 class OuterArgs(C.Structure):
     _fields_ = [("gain", GainArgs), ("ff", FfArgs), ("ro", RolloutArgs), ("admm", AdmmArgs),
-                ("J", C.c_int32), ("skip_gain", C.c_int32), ("log", C.c_void_p), ("outer_active", C.c_void_p),
-                ("timing", C.c_void_p)]
+                ("J", C.c_int32), ("skip_gain", C.c_int32), ("begin_done", C.c_int32), ("_pad", C.c_int32),
+                ("log", C.c_void_p), ("outer_active", C.c_void_p), ("timing", C.c_void_p)]
+
+
+class AdvanceArgs(C.Structure):
+    _fields_ = [("accept", AcceptArgs), ("lin", LinearizeArgs), ("exp", ExpandArgs),
+                ("admm_active", C.c_void_p), ("iters", C.c_void_p), ("lx", C.c_void_p), ("lu", C.c_void_p), ("res_prev", C.c_void_p)]
 
 
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             ("riccati_gain", "riccati_ff", "riccati_gain_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
-             "accept_step", "reduce_convergence", "reduce_convergence_table", "ilqr_admm_outer")] + \
+             "accept_step", "reduce_convergence", "reduce_convergence_table", "ilqr_admm_outer", "outer_advance")] + \
            ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_dims_supported", "isls_error_string", "isls_timing_create",
             "isls_timing_destroy", "isls_timing_reset", "isls_timing_pause", "isls_timing_read_ms"]
 
@@ -646,9 +651,12 @@ class Kernels:
         a = self.admm_args(*args, **kw)
         return self._call("admm_update", _sfx(args[0]), a, stream)
 
-    def expand_quadratic(self, Qtab, ztab, seq, u_std, c0x, c0u, xhat=None, uhat=None, Cxx=None, Cuu=None,
-                         Qr=None, Rr=None, cost=None, active=None, cost_model=COST_VIA, cost_par=None, q_nonzero=None,
-                         stream=None):
+    def expand_quadratic(self, *args, stream=None, **kw):
+        return self._call("expand_quadratic", _sfx(args[4]), self.expand_args(*args, **kw), stream)
+
+    @staticmethod
+    def expand_args(Qtab, ztab, seq, u_std, c0x, c0u, xhat=None, uhat=None, Cxx=None, Cuu=None,
+                    Qr=None, Rr=None, cost=None, active=None, cost_model=COST_VIA, cost_par=None, q_nonzero=None):
         B, N, n = c0x.shape
         m = c0u.shape[2]
         nvia = int(Qtab.shape[-3])
@@ -662,9 +670,13 @@ class Kernels:
         a.c0x, a.c0u = _ptr(_dense(c0x, (B, N, n), "c0x")), _ptr(_dense(c0u, (B, N, m), "c0u"))
         a.cost, a.active = _ptr(_dense(cost, (B,), "cost")), _ptr(active)
         a.cost_model, a.cost_par, a.q_nonzero = int(cost_model), _ptr(cost_par), _ptr(q_nonzero)
-        return self._call("expand_quadratic", _sfx(c0x), a, stream)
+        return a
 
-    def linearize(self, model, model_par, xhat, uhat, A, Bm, active=None, stream=None):
+    def linearize(self, *args, stream=None, **kw):
+        return self._call("linearize", _sfx(args[2]), self.linearize_args(*args, **kw), stream)
+
+    @staticmethod
+    def linearize_args(model, model_par, xhat, uhat, A, Bm, active=None):
         B, N, n = xhat.shape
         m = uhat.shape[2]
         a = LinearizeArgs(B=B, N=N, n=n, m=m, model=model)
@@ -675,10 +687,14 @@ class Kernels:
         a.xhat, a.uhat = _ptr(_dense(xhat, (B, N, n), "xhat")), _ptr(_dense(uhat, (B, N, m), "uhat"))
         a.A, a.Bm = _ptr(_dense(A, (B, N, n, n), "A")), _ptr(_dense(Bm, (B, N, n, m), "B"))
         a.active = _ptr(active)
-        return self._call("linearize", _sfx(xhat), a, stream)
+        return a
 
-    def accept_step(self, xx, xu, cost_new, xhat, uhat, cost, cost_hist=None, hist_len=None, tol_cost=-1.0,
-                    tol_osc=-1.0, outer_active=None, stream=None):
+    def accept_step(self, *args, stream=None, **kw):
+        return self._call("accept_step", _sfx(args[0]), self.accept_args(*args, **kw), stream)
+
+    @staticmethod
+    def accept_args(xx, xu, cost_new, xhat, uhat, cost, cost_hist=None, hist_len=None, tol_cost=-1.0,
+                    tol_osc=-1.0, outer_active=None):
         B, N, n = xx.shape
         m = xu.shape[2]
         a = AcceptArgs(B=B, N=N, n=n, m=m, tol_cost=float(tol_cost), tol_osc=float(tol_osc))
@@ -688,7 +704,22 @@ class Kernels:
         a.cost = _ptr(_dense(cost, (B,), "cost"))
         a.cost_hist, a.hist_len = _ptr(_dense(cost_hist, (B, 8), "cost_hist")), _ptr(hist_len)
         a.outer_active = _ptr(outer_active)
-        return self._call("accept_step", _sfx(xx), a, stream)
+        return a
+
+    @staticmethod
+    def advance_args(accept, lin=None, exp=None, admm_active=None, iters=None, lx=None, lu=None, res_prev=None):
+        """isls_advance_args from the blocks of accept_args / linearize_args / expand_args (lin / exp None: that stage is skipped)"""
+        a = AdvanceArgs(accept=accept)
+        if lin is not None:
+            a.lin = lin
+        if exp is not None:
+            a.exp = exp
+        a.admm_active, a.iters, a.lx, a.lu, a.res_prev = _ptr(admm_active), _ptr(iters), _ptr(lx), _ptr(lu), _ptr(res_prev)
+        a._keep = (accept, lin, exp)
+        return a
+
+    def outer_advance(self, adv, sfx, stream=None):
+        return self._call("outer_advance", sfx, adv, stream)
 
     def reduce_convergence(self, cost, res, active, status, out5, stream=None):
         fn = getattr(self.lib, f"{self.prefix}reduce_convergence_{_sfx(out5)}")
@@ -719,7 +750,7 @@ class Kernels:
             raise IslsError(f"reduce_convergence_table -> {rc}")
         return rc
 
-    def outer(self, gain, ff, ro, admm, J, sfx, skip_gain=False, log=None, outer_active=None, stream=None):
-        a = OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=int(bool(skip_gain)))
+    def outer(self, gain, ff, ro, admm, J, sfx, skip_gain=False, log=None, outer_active=None, begin_done=False, stream=None):
+        a = OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=int(bool(skip_gain)), begin_done=int(bool(begin_done)))
         a.log, a.outer_active = _ptr(log), _ptr(outer_active)
         return self._call("ilqr_admm_outer", sfx, a, stream)

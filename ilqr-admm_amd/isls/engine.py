@@ -349,8 +349,9 @@ class Engine:
                                      solve_mode=self.solve_mode, active=active, rec=rec, stream=_stream_ptr())
 
     # ---- one outer iteration, enqueued by the C driver in one call --------------------------------------------
-    def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None, ff_nseg=None):
-        """Marshal the argument block of isls_ilqr_admm_outer once; it stays valid while buffers are not re-allocated."""
+    def build_outer(self, L, J, tol_abs=0.0, tol_rel=0.0, log=None, ff_nseg=None, begin_done=False):
+        """Marshal the argument block of isls_ilqr_admm_outer once; it stays valid while buffers are not re-allocated.
+        begin_done: the caller ends every outer iteration with `advance()`, which also makes the ADMM restart of the next one."""
         K = capi.Kernels
         rec = self.ff_record()
         # with the records, nothing in this driver reads Quu / fac / Qux: the gain pass then skips those stores
@@ -371,7 +372,8 @@ class Engine:
                            tol_abs=tol_abs, tol_rel=tol_rel, res_prev=self.res_prev, active=self.admm_active,
                            iters=self.admm_iters, x_sets=self.x_sets, x_col0=self.x_col0, x_work=self.x_work,
                            u_sets=self.u_sets, u_col0=self.u_col0, u_work=self.u_work)
-        self._outer_args = capi.OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=0)
+        self._outer_args = capi.OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=0, begin_done=int(bool(begin_done)))
+        self._advance_args = None
         self._outer_args.log = capi._ptr(log)
         self._outer_args.outer_active = capi._ptr(self.outer_active)
         self._outer_log = log
@@ -391,6 +393,38 @@ class Engine:
         self.kern.accept_step(self.xx, self.xu, self.cost_new, self.xhat, self.uhat, self.cost,
                               cost_hist=self.cost_hist, hist_len=self.hist_len, tol_cost=tol_cost, tol_osc=tol_osc,
                               outer_active=self.outer_active, stream=_stream_ptr())
+
+    def begin_outer(self):
+        """The ADMM restart at the start of an outer iteration (isls/isls.py:414-415,482; admm.py:25-26) for a driver built with
+        begin_done=True: made once before the first iteration (set-up path, torch ops); `advance()` makes the later ones."""
+        act = self.outer_active.to(torch.bool)
+        self.admm_active.copy_(self.outer_active)
+        self.admm_iters.masked_fill_(act, 0)
+        for lam in (self.lx, self.lu):
+            if lam is not None:
+                lam.masked_fill_(act.view(-1, 1, 1), 0.0)
+        self.res_prev.masked_fill_(act.view(-1, 1), 1e6)
+
+    def advance(self, tol_cost=-1.0, tol_osc=-1.0, linearize=True):
+        """End of an outer iteration and start of the next in one launch (isls_outer_advance_*): accept_x_step(), the ADMM
+        restart (admm_active, lambda, residual history), then linearize() and expand() about the new nominal for the
+        trajectories still iterating.  Pair it with build_outer(..., begin_done=True).  `linearize=False` leaves A, B alone (a
+        shared LTI pair).  The cost Hessians must be the batch-shared tables (written once by expand())."""
+        K = capi.Kernels
+        key = (float(tol_cost), float(tol_osc), bool(linearize))
+        if getattr(self, "_advance_args", None) is None or self._advance_args[0] != key:
+            if not self._shared_hessian():
+                raise capi.IslsError("Engine.advance() serves the batch-shared cost Hessians; use accept_x_step / linearize / expand")
+            if getattr(self, "_hess_dirty", True):
+                self.expand()                                  # writes the shared Hessian tables once
+            acc = K.accept_args(self.xx, self.xu, self.cost_new, self.xhat, self.uhat, self.cost, cost_hist=self.cost_hist,
+                                hist_len=self.hist_len, tol_cost=tol_cost, tol_osc=tol_osc, outer_active=self.outer_active)
+            lin = K.linearize_args(self.model, self.model_par, self.xhat, self.uhat, self.A, self.Bm) if linearize else None
+            exp = K.expand_args(self.Qtab, self.ztab, self.seq, self.u_std, self.c0x, self.c0u, xhat=self.xhat, uhat=self.uhat,
+                                Qr=self.Qr, Rr=self.Rr, cost_model=self.cost_model, cost_par=self.cost_par, q_nonzero=self.q_nonzero)
+            self._advance_args = (key, K.advance_args(acc, lin, exp, admm_active=self.admm_active, iters=self.admm_iters,
+                                                      lx=self.lx, lu=self.lu, res_prev=self.res_prev))
+        self.kern.outer_advance(self._advance_args[1], self.sfx, stream=_stream_ptr())
 
     def reduce(self, table=None, rank=0):
         """[sum cost, max prim, max dual, #active, #failed] of the local shard, left on the device: in `out5`, or straight

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ISLS_VERSION 104   /* 104: isls_riccati_gain_ff_*; 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
+#define ISLS_VERSION 105   /* 105: isls_outer_advance_*, isls_outer_args.begin_done; 104: isls_riccati_gain_ff_*; 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
 
 #define ISLS_OK 0
 #define ISLS_ERR_ARG (-1)
@@ -574,6 +574,9 @@ typedef struct isls_outer_args {
     int32_t J;
     int32_t skip_gain;          /* reuse the cached factors (is_dynamics_linear && is_cost_quadratic);
                                  * when the gain pass runs and ff.seg is set, the ff operators are prepared too */
+    int32_t begin_done;         /* 1: the start-of-iteration resets described above have been made already (by
+                                 * isls_outer_advance_* at the end of the previous iteration) and are skipped here */
+    int32_t _pad;
     void *log;
     const int32_t *outer_active;
     void *timing;               /* nullable: isls_timing_create() context that records the kernel-family durations */
@@ -581,6 +584,30 @@ typedef struct isls_outer_args {
 
 int isls_ilqr_admm_outer_f64(const isls_outer_args *a, void *stream);
 int isls_ilqr_admm_outer_f32(const isls_outer_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * End of one outer iteration and start of the next in ONE launch: what the reference does between two x-step solves
+ * (isls/isls.py:488-499, then 61-66 / 95-102 / 414-415 of the next pass through the loop), per trajectory:
+ *   1. `accept`  : isls_accept_step_* semantics (nominal <- x-step, cost log, the two stop rules -> outer_active);
+ *   2. for the trajectories still iterating afterwards: admm_active <- 1, lambda <- 0, res_prev <- 1e6, iters <- 0 (the others:
+ *      admm_active <- 0) -- the resets isls_ilqr_admm_outer_* starts with (pass begin_done = 1 there);
+ *   3. `lin`     : isls_linearize_* about the new nominal   (lin.A == NULL: skipped; lin.active is ignored);
+ *   4. `exp`     : isls_expand_quadratic_* about it         (exp.c0x == NULL: skipped; exp.active is ignored).
+ * Same results as the four calls in that order with active = accept.outer_active.  lin / exp normally name accept.xhat /
+ * accept.uhat as their nominal.  admm_active, lx, lu, res_prev, iters are nullable.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_advance_args {
+    isls_accept_args accept;
+    isls_linearize_args lin;
+    isls_expand_args exp;
+    int32_t *admm_active;       /* [B] */
+    int32_t *iters;             /* [B] */
+    void *lx, *lu;              /* [B,N,n], [B,N,m] scaled duals of the ADMM */
+    void *res_prev;             /* [B,2] */
+} isls_advance_args;
+
+int isls_outer_advance_f64(const isls_advance_args *a, void *stream);
+int isls_outer_advance_f32(const isls_advance_args *a, void *stream);
 
 int isls_version(void);
 /* 1 when the kernels are instantiated for state dimension n and control dimension m (the pairs are compile-time template

@@ -13,6 +13,7 @@ extern "C" {
     int oracle_expand_quadratic_##sfx(const isls_expand_args *a);                                     \
     int oracle_linearize_##sfx(const isls_linearize_args *a);                                         \
     int oracle_accept_step_##sfx(const isls_accept_args *a);                                          \
+    int oracle_outer_advance_##sfx(const isls_advance_args *a);                                       \
     int oracle_reduce_convergence_##sfx(int32_t B, const void *cost, const void *res,                 \
                                         const int32_t *active, const int32_t *status, void *out5);    \
     int oracle_project_rows_##sfx(const isls_project_args *a);                                        \

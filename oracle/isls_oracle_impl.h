@@ -1189,7 +1189,7 @@ int FN(oracle_ilqr_admm_outer)(const isls_outer_args *a)
     const int B = a->gain.B, N = a->admm.N, n = a->admm.n, m = a->admm.m;
     /* start of an outer iteration: admm_active <- outer_active, lambda <- 0 (isls.py:414-415,482),
      * previous residual norms <- 1e6 (admm.py:25-26) for the trajectories still iterating */
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < B && !a->begin_done; ++b) {
         const int act = a->outer_active ? (a->outer_active[b] != 0) : 1;
         if (a->admm.active) a->admm.active[b] = act;
         if (!act) continue;
@@ -1205,6 +1205,37 @@ int FN(oracle_ilqr_admm_outer)(const isls_outer_args *a)
         isls_admm_args ad = a->admm;
         if ((rc = FN(oracle_admm_update)(&ad)) != ISLS_OK) return rc;
         if (a->log) memcpy((REAL *)a->log + (int64_t)j * B * 2, ad.res, sizeof(REAL) * (size_t)B * 2);
+    }
+    return ISLS_OK;
+}
+
+/* isls_outer_advance_* (include/isls_hip.h): the end of an outer iteration and the start of the next, as the plain sequence
+ * of the four steps the reference takes there -- accept (isls.py:488-499), the ADMM restart (isls.py:414-415,482,
+ * admm.py:25-26), linearisation and cost expansion about the new nominal (isls.py:61-66,95-102) for the trajectories that go on. */
+int FN(oracle_outer_advance)(const isls_advance_args *a)
+{
+    int rc;
+    const isls_accept_args *ac = &a->accept;
+    const int B = ac->B, N = ac->N, n = ac->n, m = ac->m;
+    if ((rc = FN(oracle_accept_step)(ac)) != ISLS_OK) return rc;
+    for (int b = 0; b < B; ++b) {
+        const int act = ac->outer_active ? (ac->outer_active[b] != 0) : 1;
+        if (a->admm_active) a->admm_active[b] = act;
+        if (!act) continue;
+        if (a->iters) a->iters[b] = 0;
+        if (a->lx) for (int e = 0; e < N * n; ++e) ((REAL *)a->lx)[(int64_t)b * N * n + e] = 0;
+        if (a->lu) for (int e = 0; e < N * m; ++e) ((REAL *)a->lu)[(int64_t)b * N * m + e] = 0;
+        if (a->res_prev) { ((REAL *)a->res_prev)[2 * b] = (REAL)1e6; ((REAL *)a->res_prev)[2 * b + 1] = (REAL)1e6; }
+    }
+    if (a->lin.A) {
+        isls_linearize_args l = a->lin;
+        l.active = ac->outer_active;
+        if ((rc = FN(oracle_linearize)(&l)) != ISLS_OK) return rc;
+    }
+    if (a->exp.c0x) {
+        isls_expand_args e = a->exp;
+        e.active = ac->outer_active;
+        if ((rc = FN(oracle_expand_quadratic)(&e)) != ISLS_OK) return rc;
     }
     return ISLS_OK;
 }

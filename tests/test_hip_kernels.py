@@ -685,3 +685,66 @@ def test_state_independent_linearisation_patterns(oracle, dtype):
                 torch.cuda.synchronize()
                 assert np.array_equal(Ad.cpu().numpy(), Ao) and np.array_equal(Bd.cpu().numpy(), Bo), (n, m, N, model)
                 assert np.all(Ao[1] == 7.0) and np.all(Bo[1] == 7.0)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 1e-4)])
+@pytest.mark.parametrize("which", ["di3d", "arm", "car"])
+def test_outer_advance_equals_accept_restart_linearize_expand(oracle, which, dtype, tol):
+    """isls_outer_advance_*: accept + ADMM restart + linearisation + cost expansion of the next outer iteration in one launch,
+    against the oracle's plain sequence of those four steps (isls/isls.py:488-499, 414-415, 61-66, 95-102): trajectories that
+    were frozen before, that stop in this accept (cost change below tol_cost) and that go on; integer state bit-exact."""
+    import torch
+    from dual import hip_kernels
+    from helpers import model_par, rho_to_weights
+    f = np.float64 if dtype == "f64" else np.float32
+    cfg = {"di3d": P.config2(batch=16, N=100, seed=3), "arm": P.config3(batch=16, N=100, seed=3), "car": P.config4(batch=16, N=200, seed=3)}[which]
+    B, N, n, m = 13, cfg["N"], cfg["n"], cfg["m"]
+    pa = problem_arrays(cfg, range(B), dtype=f)
+    rng = np.random.default_rng(11)
+    rn = lambda *sh: rng.standard_normal(sh).astype(f)   # noqa: E731
+    host = dict(xx=pa["xhat"] + f(0.05) * rn(B, N, n), xu=pa["uhat"] + f(0.05) * rn(B, N, m), xhat=pa["xhat"].copy(), uhat=pa["uhat"].copy(),
+                cost=(10 + rn(B)).astype(f), cost_hist=rn(B, 8), hist_len=rng.integers(1, 9, B).astype(np.int32),
+                outer_active=np.ones(B, dtype=np.int32), admm_active=rng.integers(0, 2, B).astype(np.int32),
+                iters=rng.integers(0, 9, B).astype(np.int32), lx=rn(B, N, n), lu=rn(B, N, m), res_prev=rn(B, 2),
+                A=rn(B, N, n, n), Bm=rn(B, N, n, m), c0x=rn(B, N, n), c0u=rn(B, N, m))
+    host["cost_new"] = (host["cost"] + f(0.5) * rn(B)).astype(f)
+    host["cost_new"][[2, 7]] = host["cost"][[2, 7]] + f(1e-5)         # these two meet the stop rule |cost - prev| < tol_cost
+    host["outer_active"][[1, 9]] = 0                                   # frozen before
+    Qr = rho_to_weights(0.3, N, n, f) if which != "di3d" else None
+    Rr = rho_to_weights(cfg["rho_u"], N, m, f)
+    par = model_par(cfg, f)
+
+    def run(kern, d, wrap):
+        K = capi.Kernels
+        acc = K.accept_args(d["xx"], d["xu"], d["cost_new"], d["xhat"], d["uhat"], d["cost"], cost_hist=d["cost_hist"], hist_len=d["hist_len"],
+                            tol_cost=1e-3, tol_osc=1e-3, outer_active=d["outer_active"])
+        lin = K.linearize_args(cfg["model"], wrap(par), d["xhat"], d["uhat"], d["A"], d["Bm"])
+        exp = K.expand_args(wrap(pa["Qtab"]), wrap(pa["ztab"]), wrap(pa["seq"]), cfg["u_std"], d["c0x"], d["c0u"], xhat=d["xhat"], uhat=d["uhat"],
+                            Qr=None if Qr is None else wrap(Qr), Rr=wrap(Rr))
+        adv = K.advance_args(acc, lin, exp, admm_active=d["admm_active"], iters=d["iters"], lx=d["lx"], lu=d["lu"], res_prev=d["res_prev"])
+        kern.outer_advance(adv, dtype)
+
+    ref = {k: v.copy() for k, v in host.items()}
+    keep = []
+    run(oracle, ref, lambda a: a)
+    dev = {k: torch.from_numpy(v.copy()).cuda() for k, v in host.items()}
+
+    def to_dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        keep.append(t)
+        return t
+    run(hip_kernels(), dev, to_dev)
+    torch.cuda.synchronize()
+    assert ref["outer_active"].tolist() == [1, 0, 0, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1]
+    for k, v in ref.items():
+        got = dev[k].cpu().numpy()
+        if v.dtype.kind in "iu":
+            assert np.array_equal(v, got), k
+        else:
+            err = np.max(np.abs(v.astype(np.float64) - got)) / max(1.0, float(np.max(np.abs(v))))
+            assert err < tol, f"{k}: {err:.2e}"
+    # frozen trajectories keep everything; stopped ones keep the OLD linearisation and expansion
+    for b in (1, 9, 2, 7):
+        assert np.array_equal(dev["A"].cpu().numpy()[b], host["A"][b]) and np.array_equal(dev["c0x"].cpu().numpy()[b], host["c0x"][b])
+    for b in (1, 9):
+        assert np.array_equal(dev["xhat"].cpu().numpy()[b], host["xhat"][b]) and dev["admm_active"][b].item() == 0

@@ -53,9 +53,39 @@ def run(args):
     out["lin"] = timed(eng.linearize, args.reps)
     out["expand"] = timed(eng.expand, args.reps)
     out["run_outer"] = timed(eng.run_outer, max(5, args.reps // 4))
+    import ctypes
+    from isls.engine import library
+    lib = library()
+    lib.isls_timing_create.restype = ctypes.c_void_p
+    lib.isls_timing_read_ms.restype = ctypes.c_double
+
+    def families(fn, tag):
+        """per-family kernel time inside run_outer (HIP events of the C driver) while `fn` loops"""
+        tm = ctypes.c_void_p(lib.isls_timing_create())
+        eng._outer_args.timing = tm
+        lib.isls_timing_reset(tm)
+        for _ in range(6):
+            fn()
+        torch.cuda.synchronize()
+        for kind, name in ((0, "gain"), (1, "ff"), (2, "rollout")):
+            cnt = ctypes.c_int(0)
+            ms = lib.isls_timing_read_ms(tm, kind, ctypes.byref(cnt))
+            out[f"{tag}.{name}"] = ms / max(1, cnt.value) * 1e3
+        eng._outer_args.timing = None
+        lib.isls_timing_destroy(tm)
+
     def outer():
         eng.linearize(); eng.expand(); eng.run_outer(); eng.accept_x_step(); eng.reduce()
     out["outer_it"] = timed(outer, max(5, args.reps // 4))
+    families(outer, "A")
+    if hasattr(eng, "advance"):                                # end of iteration + start of the next in one launch
+        eng.build_outer(L, J, tol_abs=0.0, tol_rel=0.0, begin_done=True)
+        eng.begin_outer()
+        out["advance"] = timed(eng.advance, args.reps)
+        def outer2():
+            eng.run_outer(); eng.advance(); eng.reduce()
+        out["outer_it2"] = timed(outer2, max(5, args.reps // 4))
+        families(outer2, "B")
     print(json.dumps({k: round(v, 1) for k, v in out.items()}))
 
 
