@@ -48,6 +48,14 @@ def _latest_pmc_file():
 PMC_FILE = _latest_pmc_file()
 
 
+def pmc_tree():
+    """The source tree the committed PMC table was measured on (written into it by tools/pmc_traffic.py)."""
+    try:
+        return json.load(open(PMC_FILE)).get("tree")
+    except (OSError, ValueError, TypeError, AttributeError):
+        return None
+
+
 def pmc_traffic(kind):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (tools/pmc_traffic.py),
     or None when no profile of this workload is available."""
@@ -88,10 +96,13 @@ def algorithmic_bytes(n, m, N, w, has_x, has_u, lti, hess_shared, records, gain_
     return [w * N * v for v in (gain, ff, ro, admm, prep)]
 
 
-def iteration_bytes(n, m, N, w, hess_shared):
-    """SURVEY 8(d) official figure: bytes_traj = w*N*[2n^2 + 2nm + m^2 + m + 7(n+m)] (fully fused ideal); the n^2 + m^2
-    of Cxx, Cuu are dropped when they are batch-shared tables ("drop the Cxx,Cuu terms when they are shared")."""
-    return w * N * (2 * n * n + 2 * n * m + m * m + m + 7 * (n + m) - (n * n + m * m if hess_shared else 0))
+def iteration_bytes(n, m, N, w, hess_shared, has_x=True, has_u=True):
+    """SURVEY 8(d) official figure: bytes_traj = w*N*[2n^2 + 2nm + m^2 + m + 7(n+m)] (fully fused ideal).  Of the 7(n+m), 3(n+m)
+    are cx,cu in, xhat,uhat in and out; 4(n+m) are z, lambda in and out, which exist only for the constrained blocks (config 2
+    constrains u alone: 4m); the n^2 + m^2 of Cxx, Cuu are dropped when they are batch-shared tables ("drop the
+    Cxx,Cuu terms when they are shared")."""
+    zl = 4 * ((n if has_x else 0) + (m if has_u else 0))
+    return w * N * (2 * n * n + 2 * n * m + m * m + m + 3 * (n + m) + zl - (n * n + m * m if hess_shared else 0))
 
 
 def spawn_ranks(n_gpus):
@@ -103,13 +114,17 @@ def spawn_ranks(n_gpus):
     if have < n_gpus and not REHEARSAL:
         sys.exit(f"bench.py: --gpus {n_gpus} requested but only {have} HIP device(s) are visible; refusing to print a "
                  f"{n_gpus}-GPU line from fewer devices")
+    if REHEARSAL and have < 1:
+        sys.exit("bench.py: the rehearsal needs one HIP device")
     with socket.socket() as so:                                # a free rendezvous port on the loopback interface
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: RCCL needs it on this driver
+    # dmabuf IPC: this image's host driver supports no legacy IPC handles, and RCCL / cross-process device memory fail with
+    # `hipIpcGetMemHandle: invalid argument` without it (the image exports it already; kept for environments built by hand)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -127,6 +142,8 @@ def main():
     ap.add_argument("--separate-launches", action="store_true",
                     help="A/B: accept, ADMM restart, linearisation and expansion as four launches instead of isls_outer_advance")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories in the CPU-baseline sample (0: auto)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+                    help="2: the headline workload (default); 3: 3R arm, state + control boxes; 4: car, control box + keep-out rectangles")
     ap.add_argument("--config5", action="store_true", help="secondary workload: SLS-ADMM with chance constraints (B=8192, N=50)")
     ap.add_argument("--config5-dim", type=int, default=1, help="double integrator dimension of the config-5 workload (1 or 3)")
     ap.add_argument("--isls-admm", action="store_true", help="secondary workload: iSLS.isls_admm on the 3R arm with robust control bounds")
@@ -135,6 +152,8 @@ def main():
         return config5_main(args)
     if args.isls_admm:
         return isls_admm_main(args)
+    if args.config in (3, 4):
+        return secondary_config_main(args)
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -154,10 +173,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        if REHEARSAL:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            if REHEARSAL:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        except Exception as exc:                               # a rank that cannot join says why and fails the launch
+            print(f"bench.py: rank {rank}: init_process_group failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+            sys.exit(3)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -286,7 +309,8 @@ def main():
         w = 8
         records = eng.ff_record() is not None
         gain_ff = fam[1][1] < fam[2][1]                         # fewer ff launches than rollouts: the first pass rode on the gain pass
-        abytes = algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=args.lti, hess_shared=hess_shared, records=records,
+        has_x, has_u = eng.zx is not None, eng.zu is not None
+        abytes = algorithmic_bytes(n, m, N, w, has_x=has_x, has_u=has_u, lti=args.lti, hess_shared=hess_shared, records=records,
                                    gain_ff=gain_ff)
         nseg_ff = max(1, int(eng._outer_args.ff.seg.nseg))
         abytes[4] = abytes[4] * (nseg_ff - 1) / nseg_ff          # the operators cover every segment but the last
@@ -295,7 +319,7 @@ def main():
         default_workload = (B, N, J, L) == (4096, 100, 5, 20) and not args.lti
         avg_ms = fam[dom][0] / max(1, fam[dom][1])
         achieved = abytes[dom] * B / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        it_bytes = iteration_bytes(n, m, N, w, hess_shared) * B
+        it_bytes = iteration_bytes(n, m, N, w, hess_shared, has_x=has_x, has_u=has_u) * B
         # every kernel family against the same HBM figure (algorithmic bytes / event-timed launch) with the PMC-measured
         # traffic of the committed profile next to it: the rollout is issue bound, the feed-forward pass is the one that streams
         families = {}
@@ -329,6 +353,7 @@ def main():
                          # every kernel family against the same HBM figure (algorithmic bytes / event-timed launch): the
                          # rollout is issue bound, the feed-forward pass is the one that streams
                          "pmc_profile": os.path.basename(PMC_FILE) if (PMC_FILE and default_workload) else None,
+                         "pmc_tree": pmc_tree() if default_workload else None,
                          "families": families},
             "kernels_ms_per_step": {KIND_NAMES[k]: fam[k][0] / sampled for k in range(5)},
             "launches_per_step": {KIND_NAMES[k]: fam[k][1] / sampled for k in range(5)},
@@ -337,13 +362,138 @@ def main():
                             "max_dual": float(red_host[:, 2].max()), "active": float(red_host[:, 3].sum()),
                             "failed": float(red_host[:, 4].sum())},
         }
+        # what the collective layer saw: ranks that joined the process group (1 without one) and the RCCL build
+        out["n_ranks_joined"] = int(dist.get_world_size()) if dist is not None else 1
+        out["collective_backend"] = (dist.get_backend() if dist is not None else None)
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            out["rccl_version"] = None
         if REHEARSAL:
             out["rehearsal"] = True                             # N ranks on one device over gloo: exercises the code path, measures nothing
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, args, B, N, n, m, J, L)
+        # the CPU baseline is timed on rank 0 at N = 1 only (the key is present, null, on the N > 1 lines)
+        out["cpu_baseline"] = cpu_baseline(cfg, args, B, N, n, m, J, L) if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+# ---- configs 3 and 4 (`--config 3|4`): the nonlinear workloads of BASELINE.json at their full per-GPU size ---------------------
+def secondary_config_main(args):
+    """`bench.py --config 3`: 3R planar arm (n = 9, m = 3, N = 100, B = 4096), state + control boxes, J = 10 ADMM iterations x
+    L = 5 candidates (notebooks/3DoF robot/State and control bound constraints.ipynb cells 22-23).
+    `bench.py --config 4`: car (n = 4, m = 2, N = 200, B = 4096 per GPU), control box + two keep-out rectangles on the
+    position (project_set_convex over the 200 position rows), J = 5 x L = 20 (notebooks/Car/Iterative LQR with state
+    constraints.ipynb cell 18).  Same step as the headline (one C-driver call + isls_outer_advance + the reduction), early
+    exit off; one JSON line with `roofline` of the dominant kernel family and `cpu_baseline` (the oracle on a sample)."""
+    from isls import Box
+    from isls import _capi as capi
+    from isls.engine import library
+    import isls_problems as P
+    from test_full_size import _make
+    pj = sys.modules["isls.projections"]
+    torch.cuda.set_device(0)
+    B = args.batch
+    if args.config == 3:
+        cfg = P.config3(batch=B, N=100, seed=0)
+        N, L, J = 100, cfg["max_line_search"], cfg["max_admm_iter"]
+        proj = dict(project_x=Box(cfg["x_lo"], cfg["x_hi"]), project_u=Box(cfg["u_lo"], cfg["u_hi"]), rho_x=cfg["rho_x"], rho_u=cfg["rho_u"])
+        label = "config3: 3R planar arm iLQR-ADMM (DP form), boxes on joint velocities, final end-effector x and u"
+    else:
+        cfg = P.config4(batch=B, N=200, seed=0)
+        N, L, J = 200, 20, 5
+        rho_x = np.zeros((N, 4, 4)); rho_x[:, :2, :2] = 0.1 * np.eye(2)
+        cs = pj.keepout_rectangles(4, [[-7.0, -3.0], [-3.0, -7.0]], [[2.0, 1.0], [2.0, 1.0]], -np.pi / 4)
+        proj = dict(project_x=cs, project_u=Box(cfg["u_lo"], cfg["u_hi"]), rho_x=rho_x, rho_u=cfg["rho_u"])
+        label = "config4: car iLQR-ADMM (DP form), control box + two keep-out rectangles on the position"
+    n, m = cfg["n"], cfg["m"]
+    s = _make(cfg, range(B))
+    s._setup_admm(proj["project_x"], proj["project_u"], proj["rho_x"], proj["rho_u"], 1.0)
+    e = s.engine
+    e.outer_active.fill_(1)
+    e.build_outer(L, J, tol_abs=0.0, tol_rel=0.0, begin_done=True)
+    e.linearize(); e.expand(); e.begin_outer()
+    lib = library()
+
+    def step():
+        e.run_outer()
+        e.advance()
+        e.reduce()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timing = lib.isls_timing_create()
+    e._outer_args.timing = timing
+    lib.isls_timing_reset(timing)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lib.isls_timing_pause(timing, 0 if i % EVENT_PERIOD == 0 else 1)
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    e._outer_args.timing = None
+    fam = []
+    for kind in range(5):
+        cnt = ctypes.c_int(0)
+        fam.append((lib.isls_timing_read_ms(timing, kind, ctypes.byref(cnt)), cnt.value))
+    lib.isls_timing_destroy(timing)
+    st = e.status.cpu().numpy()
+    w, has_x, has_u = 8, e.zx is not None, e.zu is not None
+    hess_shared = bool(e._shared_hessian())
+    gain_ff = fam[1][1] < fam[2][1]
+    abytes = algorithmic_bytes(n, m, N, w, has_x=has_x, has_u=has_u, lti=False, hess_shared=hess_shared, records=e.ff_record() is not None,
+                               gain_ff=gain_ff)
+    sampled = len(range(0, args.steps, EVENT_PERIOD))
+    dom = int(np.argmax([ms for ms, _ in fam]))
+    families = {}
+    for k in range(5):
+        avg = fam[k][0] / max(1, fam[k][1])
+        ach = abytes[k] * B / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        families[KIND_NAMES[k]] = {"avg_launch_ms": avg, "launches_per_step": fam[k][1] / sampled, "ms_per_step": fam[k][0] / sampled,
+                                   "algorithmic_bytes_per_launch": abytes[k] * B, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+    it_per_s = args.steps / dt
+    it_bytes = iteration_bytes(n, m, N, w, hess_shared, has_x=has_x, has_u=has_u) * B
+    out = {"metric": f"iLQR-ADMM iterations/sec (config {args.config})", "value": it_per_s, "unit": "iterations/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": label, "batch_per_gpu": B, "horizon": N, "x_dim": n, "u_dim": m, "admm_iters_J": J, "line_search_L": L,
+                      "layout": "time-varying A,B per trajectory (device linearisation)", "early_exit": False,
+                      "state_constraint": "box" if args.config == 3 else "project_set_convex over two keep-out rectangles (device)",
+                      "trajectory_iterations_per_s": it_per_s * B, "status_bits_set": int((st != 0).sum())},
+           "roofline": {"bound": "hbm", "kernel": KIND_NAMES[dom], "achieved": families[KIND_NAMES[dom]]["achieved"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": families[KIND_NAMES[dom]]["frac"], "traffic": None,
+                        "avg_launch_ms": families[KIND_NAMES[dom]]["avg_launch_ms"],
+                        "algorithmic_bytes_per_launch": abytes[dom] * B, "iteration_algorithmic_bytes": it_bytes,
+                        "iteration_frac": it_bytes * it_per_s / 1e9 / HBM_PEAK_GBS, "families": families},
+           "cpu_baseline": None}
+    if not args.no_cpu_baseline:
+        from helpers import OracleDriver, problem_arrays
+        from oracle import oracle as orc
+        kern, olib = orc.load()
+        cores = orc.set_threads(olib, host_cores())
+        sample = args.cpu_sample or min(B, 256)
+        scfg = P.config3(batch=sample, N=N, seed=0) if args.config == 3 else P.config4(batch=sample, N=N, seed=0)
+        pa = problem_arrays(scfg, range(sample))
+        if args.config == 3:
+            d = OracleDriver(kern, pa, rho_x=scfg["rho_x"], rho_u=scfg["rho_u"], project_x=True)
+        else:
+            d = OracleDriver(kern, pa, rho_x=proj["rho_x"], rho_u=scfg["rho_u"], project_x=True, x_sets=proj["project_x"])
+        d.run(1, L, J, 0.0)
+        d.outer_active[:] = 1
+        reps, t1 = 0, time.perf_counter()
+        while True:
+            d.run(1, L, J, 0.0)
+            d.outer_active[:] = 1                              # the natural stop rules are not part of the timed work
+            reps += 1
+            el = time.perf_counter() - t1
+            if el > 12.0 or reps >= 200:
+                break
+        tps = sample * reps / el
+        out["cpu_baseline"] = {"value": tps / B, "unit": "iterations/s", "cores": cores, "kind": "port",
+                               "sample": f"{reps} outer iterations (J={J}, L={L}) of {sample} trajectories of the same workload through the "
+                                         f"oracle's kernels, {el:.1f} s, scaled linearly to batch {B}",
+                               "trajectory_iterations_per_s": tps}
+    print(json.dumps(out))
 
 
 # ---- config 5 (SLS-ADMM with chance constraints): secondary workload, `--config5` ----------------------------------------

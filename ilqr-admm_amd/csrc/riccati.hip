@@ -151,11 +151,17 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
 
     // ---- global load plan: per-lane bases (trajectory, own elements) fixed for the horizon; a step adds the uniform t * stride
     const bool has_cux = p.Cux.p != nullptr;
+    // (when the slot's lanes tile an array exactly -- n = 6, m = 3: 36 = 4 x 9, 18 = 2 x 9 -- no element needs the clamp and the
+    // lane's loads are ONE base plus compile-time offsets: one address register per array instead of one per load)
+#ifndef ISLS_GAIN_EXACT
+#define ISLS_GAIN_EXACT 1
+#endif
+    constexpr bool A_EXACT = ISLS_GAIN_EXACT && (NX * NX) % G == 0, B_EXACT = ISLS_GAIN_EXACT && (NX * NU) % G == 0;
     const T *pA[JA], *pB[JB];
 #pragma unroll
-    for (int j = 0; j < JA; ++j) { const int e = i + G * j; pA[j] = p.A.at(bb, 0) + (e < NX * NX ? e : NX * NX - 1); }
+    for (int j = 0; j < JA; ++j) { const int e = i + G * j; pA[j] = p.A.at(bb, 0) + (A_EXACT ? e : (e < NX * NX ? e : NX * NX - 1)); }
 #pragma unroll
-    for (int j = 0; j < JB; ++j) { const int e = i + G * j; pB[j] = p.Bm.at(bb, 0) + (e < NX * NU ? e : NX * NU - 1); }
+    for (int j = 0; j < JB; ++j) { const int e = i + G * j; pB[j] = p.Bm.at(bb, 0) + (B_EXACT ? e : (e < NX * NU ? e : NX * NU - 1)); }
     // row i of the cost Hessian stack: [Cxx[i,:]] or [Cux[a,:] Cuu[a,:]].  Raw, unconditional loads: x-lanes never use the
     // columns >= NX of crow; u-lanes without a Cux array read Cxx instead and the step multiplies that part by zero
     const T *pcl = xl ? p.Cxx.at(bb, 0) + i * NX : (has_cux ? p.Cux.at(bb, 0) + a_row * NX : p.Cxx.at(bb, 0));
@@ -248,8 +254,8 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         T c0, hv, zv, lv;                                      // FF form
     };
 #ifndef ISLS_GAIN_RING
-#define ISLS_GAIN_RING D
-#endif
+#define ISLS_GAIN_RING 1                                        // one step ahead covers an HBM round trip (a step takes ~2 us); two cost 38 registers per
+#endif                                                          // lane, which the compiler parks in AGPRs and copies back every step (212 -> 205 us)
     constexpr int RD = ISLS_GAIN_RING;                          // steps of operands in flight (<= D: the unrolled group)
     static_assert(RD >= 1 && RD <= D, "ring depth");
     Stage ring[RD];
@@ -588,6 +594,27 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                 for (int r = 0; r < NU; ++r) sacc += Kc[r] * Quu[r][c];
                 Wr[c] = sacc;
             }
+#ifndef ISLS_GAIN_JOSEPH2
+#define ISLS_GAIN_JOSEPH2 1
+#endif
+#if ISLS_GAIN_JOSEPH2
+            // the same four terms with (K'Quu) K and Qux'K under one sum: ((K'Quu)_i. + Qux_.i) . K_.j + K_.i . Qux_.j -- the first
+            // bracket is the residual of Quu K = -Qux, so the value keeps the form's insensitivity to the rounding of K (two
+            // multiply-adds per (r, j) instead of three)
+            T Gr[NU];
+#pragma unroll
+            for (int r = 0; r < NU; ++r) Gr[r] = Wr[r] + rhs[r];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                T t12 = T(0), t3 = T(0);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+                    t12 += Gr[r] * Kr[r][j];                   // (K'Quu + Qux') K
+                    t3 += Kc[r] * Qxr[r][j];                   // K' Qux
+                }
+                rec[vdst + j] = (M[j] + t3) + t12;
+            }
+#else
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 T t1 = T(0), t2 = T(0), t3 = T(0);
@@ -601,6 +628,7 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
                 const T vn = (MODE == ISLS_SOLVE_CHOL) ? ((M[j] + t1) + t2) + t3 : ((M[j] + t2) + t3) + t1;
                 rec[vdst + j] = vn;
             }
+#endif
         }
     };
 

@@ -350,17 +350,7 @@ class iSLS(Base):
         L = max_line_search if max_line_search is not None else max_line_search_iter
         tol = threshold if threshold is not None else tol
         e = self.engine
-        px, pu = self._projection(project_x, self.x_dim), self._projection(project_u, self.u_dim)
-        on_device = (Box, ConvexSets)
-        host_proj = (px is not None and not isinstance(px, on_device)) or (pu is not None and not isinstance(pu, on_device))
-        host_proj = host_proj or self._host_ls                  # a host line search: the whole ADMM loop is host driven
-        xs = px if isinstance(px, ConvexSets) and not host_proj else None
-        us = pu if isinstance(pu, ConvexSets) and not host_proj else None
-        xb = px.bounds(self.N, self.x_dim) if isinstance(px, Box) else ((-np.inf, np.inf) if px is not None and xs is None else None)
-        ub = pu.bounds(self.N, self.u_dim) if isinstance(pu, Box) else ((-np.inf, np.inf) if pu is not None and us is None else None)
-        zx_keep, zu_keep = e.zx, e.zu
-        e.set_admm(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None,
-                   x_box=xb, u_box=ub, relax=alpha, x_sets=xs, u_sets=us)
+        px, pu, host_proj = self._setup_admm(project_x, project_u, rho_x, rho_u, alpha)
         J = int(max_admm_iter)
         logbuf = torch.zeros(J, self.batch, 2, dtype=e.dtype, device=e.device)
         e.outer_active.fill_(1)
@@ -389,6 +379,22 @@ class iSLS(Base):
         # `self.admm_iters` tells how many are real per trajectory
         self.admm_iters = e.admm_iters.cpu().numpy()
         return logs[:int(self.admm_iters[0])] if self.batch == 1 and not host_proj else logs
+
+    def _setup_admm(self, project_x, project_u, rho_x, rho_u, alpha):
+        """project_x / project_u of an ilqr_admm call -> the engine's ADMM state (weights, boxes or device sets, z / lambda
+        buffers); returns (px, pu, host_proj): the projections as objects and whether the z-step runs through the host."""
+        e = self.engine
+        px, pu = self._projection(project_x, self.x_dim), self._projection(project_u, self.u_dim)
+        on_device = (Box, ConvexSets)
+        host_proj = (px is not None and not isinstance(px, on_device)) or (pu is not None and not isinstance(pu, on_device))
+        host_proj = host_proj or self._host_ls                  # a host line search: the whole ADMM loop is host driven
+        xs = px if isinstance(px, ConvexSets) and not host_proj else None
+        us = pu if isinstance(pu, ConvexSets) and not host_proj else None
+        xb = px.bounds(self.N, self.x_dim) if isinstance(px, Box) else ((-np.inf, np.inf) if px is not None and xs is None else None)
+        ub = pu.bounds(self.N, self.u_dim) if isinstance(pu, Box) else ((-np.inf, np.inf) if pu is not None and us is None else None)
+        e.set_admm(rho_x=rho_x if px is not None else None, rho_u=rho_u if pu is not None else None,
+                   x_box=xb, u_box=ub, relax=alpha, x_sets=xs, u_sets=us)
+        return px, pu, host_proj
 
     def _expand_regularised(self, get_Cs):
         """Quadratic expansion about the nominal plus the ADMM regulariser's Hessians: on the device for the built-in costs,
