@@ -25,7 +25,7 @@ struct ProjP {
 template <typename T, int D, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 2 : 1)) void project_rows_kernel(ProjP<T> p)
 {
-    __shared__ T red[2][16];
+    __shared__ T red[2][2][16];                                // [parity][a / b][wavefront]
     const int pb = blockIdx.x, r = threadIdx.x;
     if (p.active != nullptr && p.active[pb] == 0) return;      // uniform per workgroup
     const bool inr = r < p.R;
@@ -53,15 +53,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 2 : 1)) void project_rows_ke
         for (int j = 0; j < D; ++j) x[j] = v[j];
     } else {
         const int nw = (blockDim.x + 63) >> 6, wid = r >> 6;
+        // Workgroup-wide maxima once per inner iteration.  One wavefront (R <= 64): the butterfly's result is the answer, no
+        // LDS, no barrier.  Several: ONE barrier per call -- the partials alternate between two buffers, and a buffer is
+        // rewritten two calls later, behind the barrier of the call in between, which no thread passes before it has read it.
+        int par = 0;
         auto block_max = [&](T &a, T &b) {
             if (!row) { a = T(0); b = T(0); }
             a = wave_max(a);
             b = wave_max(b);
-            if ((r & 63) == 0) { red[0][wid] = a; red[1][wid] = b; }
+            if (nw == 1) return;
+            if ((r & 63) == 0) { red[par][0][wid] = a; red[par][1][wid] = b; }
             __syncthreads();
-            T ma = red[0][0], mb = red[1][0];
-            for (int w = 1; w < nw; ++w) { ma = red[0][w] > ma ? red[0][w] : ma; mb = red[1][w] > mb ? red[1][w] : mb; }
-            __syncthreads();
+            T ma = red[par][0][0], mb = red[par][1][0];
+            for (int w = 1; w < nw; ++w) { ma = red[par][0][w] > ma ? red[par][0][w] : ma; mb = red[par][1][w] > mb ? red[par][1][w] : mb; }
+            par ^= 1;
             a = ma;
             b = mb;
         };

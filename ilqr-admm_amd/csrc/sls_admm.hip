@@ -30,7 +30,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
 {
     extern __shared__ __align__(16) unsigned char sls_smem[];
     T *rhs = reinterpret_cast<T *>(sls_smem);                  // [R][D]
-    __shared__ T red[2][16];
+    __shared__ T red[2][2][16];                                // [parity][a / b][wavefront]
     const int pb = blockIdx.x, r = threadIdx.x, R = p.R;
     const bool row = r < R;
     const int rr_i = row ? r : 0;
@@ -44,16 +44,21 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
         sets[s].b = p.b[s] ? p.b[s] + (int64_t)pb * p.b_sp[s] : nullptr;
         sets[s].par = p.par[s] ? p.par[s] + (int64_t)pb * p.par_sp[s] : nullptr;
     }
-    // workgroup-wide max (project_set_convex) and sum (residual norms); idle threads contribute zeros
+    // workgroup-wide max (project_set_convex: once per inner iteration) and sum (residual norms); idle threads contribute
+    // zeros.  One wavefront (R <= 64, DI-1D): the butterfly is the answer -- no LDS, no barrier.  Several: ONE barrier per call:
+    // the partials alternate between two buffers, and a buffer is rewritten two calls later, behind the barrier of the call
+    // in between, which no thread passes before it has read it.
+    int par = 0;
     auto block_max = [&](T &a, T &b) {
         if (!row) { a = T(0); b = T(0); }
         a = wave_max(a);
         b = wave_max(b);
-        if ((r & 63) == 0) { red[0][wid] = a; red[1][wid] = b; }
+        if (nw == 1) return;
+        if ((r & 63) == 0) { red[par][0][wid] = a; red[par][1][wid] = b; }
         __syncthreads();
-        T ma = red[0][0], mb = red[1][0];
-        for (int w = 1; w < nw; ++w) { ma = red[0][w] > ma ? red[0][w] : ma; mb = red[1][w] > mb ? red[1][w] : mb; }
-        __syncthreads();
+        T ma = red[par][0][0], mb = red[par][1][0];
+        for (int w = 1; w < nw; ++w) { ma = red[par][0][w] > ma ? red[par][0][w] : ma; mb = red[par][1][w] > mb ? red[par][1][w] : mb; }
+        par ^= 1;
         a = ma;
         b = mb;
     };
@@ -61,11 +66,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
         if (!row) { a = T(0); b = T(0); }
         a = wave_sum(a);
         b = wave_sum(b);
-        if ((r & 63) == 0) { red[0][wid] = a; red[1][wid] = b; }
+        if (nw == 1) return;
+        if ((r & 63) == 0) { red[par][0][wid] = a; red[par][1][wid] = b; }
         __syncthreads();
         T sa = T(0), sb = T(0);
-        for (int w = 0; w < nw; ++w) { sa += red[0][w]; sb += red[1][w]; }
-        __syncthreads();
+        for (int w = 0; w < nw; ++w) { sa += red[par][0][w]; sb += red[par][1][w]; }
+        par ^= 1;
         a = sa;
         b = sb;
     };

@@ -157,6 +157,10 @@ class _LaggedAny:
         self.dev = torch.ones(max(1, n), dtype=torch.int32, device=device)
         self.ev = []
 
+    def reset(self):
+        """start a new sequence of flags on the same buffers (the previous sequence's copies have been queued before)"""
+        self.ev = []
+
     def push(self, mask):
         i = len(self.ev)
         self.dev[i] = mask.any()
@@ -206,13 +210,27 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     L = int(max_line_search)
     logbuf = torch.zeros(J, B, 2, dtype=e.dtype, device=e.device)
     e.outer_active.fill_(1)
-    Hlog = np.full((B, int(k_max) + 1), np.nan)                                # cost history per problem (column 0: initial cost)
-    Hlog[:, 0] = np.atleast_1d(np.asarray(self.cost, dtype=np.float64))
-    n_hist = np.ones(B, dtype=np.int64)
+    # Outer-loop state stays on the device: the cost of every outer iteration goes into `costlog` (read once at the end), the
+    # two stop rules (isls.py:695-701) run in isls_accept_step on the cost history, and the host looks at `outer_active` only
+    # through flags that have already landed in pinned memory -- it never waits for the GPU inside the loop, so the kernels
+    # of outer iteration k + 1 are queued while those of k still run (round 2 read status, cost and the active mask back
+    # after every outer iteration: 7.4 ms of wall time for 3.6-4.7 ms of kernels).  A batch that went inactive may therefore
+    # see an outer iteration or two more; their kernels skip every problem.
+    costlog = torch.zeros(int(k_max) + 1, B, dtype=e.dtype, device=e.device)
+    costlog[0].copy_(e.cost)
+    e.cost_hist.zero_()
+    e.cost_hist[:, 0] = e.cost
+    e.hist_len.fill_(1)
     mask3 = lambda a: a.to(torch.bool).view(B, 1, 1)                          # noqa: E731
     device_only = not self._host_ls and all(blk is None or blk["desc"] is not None for blk in cs.blocks.values())
-    graph = dict(g=None, eager_done=False) if (device_only and cs.constrained and e.profile_events is None and
-                                               os.environ.get("ISLS_ADMM_GRAPH", "1") != "0") else None
+    graph = dict(g=None, eager_done=False, ptrs=None) if (device_only and cs.constrained and e.profile_events is None and
+                                                          os.environ.get("ISLS_ADMM_GRAPH", "1") != "0") else None
+    host_sync = self._host_ls or self._host_cost or not device_only or verbose   # host callbacks need the numbers anyway
+    outer_count = torch.zeros(B, dtype=torch.int32, device=e.device)
+    outer_lag = _LaggedAny(e.device, int(k_max))
+    inner_lag = _LaggedAny(e.device, J)
+    ran = 0
+
     def captured_pointers():
         """device addresses a recorded ADMM iteration reads or writes through engine attributes a callback may replace"""
         ts = [e.A, e.Bm, e.c0x, e.c0u, e.K, e.Qr, e.Rr, e.xhat, e.uhat, e.xx, e.xu, e.Qtab, e.ztab, e.model_par, e.cost_par,
@@ -220,6 +238,7 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
         return tuple(None if t is None else t.data_ptr() for t in ts)
 
     for k in range(k_max):
+        outer_count.add_(e.outer_active)
         self._linearize(get_AB)
         self._expand_regularised(get_Cs)                                        # built-in cost on the device, else the caller's get_Cs (isls.py:548-560)
         cs.prepare(e.outer_active)
@@ -228,7 +247,7 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
             # graph holds the old addresses -- drop it, run eagerly once, record again
             graph.update(g=None, eager_done=False)
         cs.restart(e.outer_active)                                              # lmb restarts, z is warm-started (isls.py:613-616)
-        lag = _LaggedAny(e.device, J)
+        inner_lag.reset()
         act = e.admm_active
 
         def admm_iteration():
@@ -280,11 +299,9 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
                 e.admm_iters.add_(act)
                 break
             logbuf[j].copy_(e.res)
-            lag.push(act)
-            if lag.seen_all_inactive():
+            inner_lag.push(act)
+            if inner_lag.seen_all_inactive():
                 break
-        for jd in lag.dead_rows():
-            logbuf[jd].zero_()                                                  # ran on no problem: no log row
         # new nominal: x_nom + d_x, u_nom + d_u of the last x-step (isls.py:684-687); the setter evaluates its cost
         oa = mask3(e.outer_active)
         e.xhat.copy_(torch.where(oa, e.xhat + dx[0], e.xhat))
@@ -292,33 +309,45 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
         e.evaluate_cost()
         if self._host_cost:
             self._refresh_host_cost()
-        st = e.status.cpu().numpy()
-        if (st & capi.ST_NOT_PD).any():
-            raise np.linalg.LinAlgError("Quu not positive definite")
-        cost = e.cost.cpu().numpy().astype(np.float64)
-        self.cost_log.append(self.cost)
-        active = e.outer_active.cpu().numpy().astype(bool)
-        # every problem still iterating has the same history length (k + 2 entries after this append): the two stop rules are
-        # evaluated for all of them at once -- a Python loop over a thousand problems cost more than the ADMM iterations
-        ia = np.nonzero(active)[0]
-        if verbose:
-            for b in ia:
-                print("Iteration number ", k, "iSLS cost: ", cost[b])
-        prev = Hlog[ia, k]
-        Hlog[ia, k + 1] = cost[ia]
-        stop = np.abs(cost[ia] - prev) < 1e-4                                   # isls.py:695-697
-        if k + 2 >= 5:                                                          # oscillation test, isls.py:699-701
-            h = Hlog[ia, :k + 2]
-            osc = np.abs(h[:, -4:].mean(1) - h[:, -8:-4].mean(1)) < 1e-3        # hist[-8:-4] is shorter on short logs, like the slice
-            stop = stop | osc
-        active[ia] = ~stop
-        n_hist[ia] += 1
-        e.outer_active.copy_(torch.as_tensor(active.astype(np.int32), device=e.device))
-        if not active.any():
+        ran = k + 1
+        # cost log entry of this outer iteration and the two stop rules (|cost - prev| < 1e-4, isls.py:695-697; oscillation of
+        # the last eight costs < 1e-3, isls.py:699-701) on the device: isls_accept_step with the nominal as its own x-step
+        e.cost_new.copy_(e.cost)
+        e.cost.copy_(costlog[k])                                                # `prev` of the rule: the cost before this iteration
+        e.cost.copy_(torch.where(e.outer_active.to(torch.bool), e.cost, e.cost_new))
+        costlog[k + 1].copy_(e.cost_new)
+        e.kern.accept_step(e.xhat, e.uhat, e.cost_new, e.xhat, e.uhat, e.cost, cost_hist=e.cost_hist, hist_len=e.hist_len,
+                           tol_cost=1e-4, tol_osc=1e-3, outer_active=e.outer_active, stream=_stream_ptr())
+        e.cost.copy_(e.cost_new)
+        outer_lag.push(e.outer_active)
+        if host_sync:
+            st = e.status.cpu().numpy()
+            if (st & capi.ST_NOT_PD).any():
+                raise np.linalg.LinAlgError("Quu not positive definite")
+            if verbose:
+                cost = e.cost.cpu().numpy()
+                for b_ in np.nonzero(e.outer_active.cpu().numpy())[0]:
+                    print("Iteration number ", k, "iSLS cost: ", cost[b_])
+            if not bool(e.outer_active.any().item()):
+                break
+        elif outer_lag.seen_all_inactive():
             break
-    self.admm_iters = e.admm_iters.cpu().numpy()
+    # ---- one synchronisation for the whole call -----------------------------------------------------------------------
+    st = e.status.cpu().numpy()
+    if (st & capi.ST_NOT_PD).any():
+        raise np.linalg.LinAlgError("Quu not positive definite")
+    dead = outer_lag.dead_rows()                                                # outer iterations that ran on no problem
+    ran = ran - len([d for d in dead if d < ran])
+    cl = costlog[:ran + 1].cpu().numpy().astype(np.float64)
+    self.outer_iters = outer_count.cpu().numpy().astype(np.int64)              # outer iterations every problem took part in
+    for k_ in range(ran):
+        self.cost_log.append(cl[k_ + 1] if B > 1 else float(cl[k_ + 1][0]))
+    # log rows of ADMM iterations that ran on no problem are not the reference's
+    iters_h = e.admm_iters.cpu().numpy()
+    for jd in range(int(iters_h.max()) if iters_h.size else 0, J):
+        logbuf[jd].zero_()
+    self.admm_iters = iters_h
     self.admm_logs = logbuf.cpu().numpy()
-    self.outer_iters = n_hist - 1
     self._dx_columns, xu = cs.columns()
     du_out, phi_out = xu[..., 0], xu[..., 1:]
     return (du_out[0], phi_out[0]) if B == 1 else (du_out, phi_out)
