@@ -274,6 +274,8 @@ ISLS_API int isls_version(void) { return ISLS_VERSION; }
 
 ISLS_API int32_t isls_dims_supported(int32_t n, int32_t m) { return dims_supported(n, m) ? 1 : 0; }
 
+ISLS_API int32_t isls_dims_generic(int32_t n, int32_t m) { return dims_generic(n, m) ? 1 : 0; }
+
 ISLS_API const char *isls_error_string(int code)
 {
     switch (code) {

@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256) void ff_stitch_kernel(int B, int N, int nseg, 
 {
     constexpr int TB = kStitchTraj;
     __shared__ T vin[TB][kMaxFfSeg][NX];                       // vin[.][s] = v entering segment s (s <= nseg-2)
+    // feedback column blockIdx.y (isls_ff_args.ncol): its own segment-start values and k; G and Psi are shared by the columns
+    vseg += (int64_t)blockIdx.y * B * nseg * NX;
+    k += (int64_t)blockIdx.y * B * N * NU;
     const int tid = threadIdx.x;
     const int tr = tid / NX, i = tid - tr * NX;
     const int b = blockIdx.x * TB + tr;
@@ -418,7 +421,7 @@ int launch_ff_stitch(const isls_ff_args &a, hipStream_t s)
     if (!seg_ok(a.seg, a.N)) return ISLS_ERR_ARG;
     const int grid = (a.B + kStitchTraj - 1) / kStitchTraj;
 #define CALL(NX_, NU_)                                                                                         \
-    hipLaunchKernelGGL((ff_stitch_kernel<T, NX_, NU_>), dim3(grid), dim3(256), 0, s, a.B, a.N, a.seg.nseg,     \
+    hipLaunchKernelGGL((ff_stitch_kernel<T, NX_, NU_>), dim3(grid, a._pad > 1 ? a._pad : 1), dim3(256), 0, s, a.B, a.N, a.seg.nseg, \
                        a.seg.seg_len, (const T *)a.seg.G, (const T *)a.seg.Psi, (const T *)a.seg.v, (T *)a.k, a.active);
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL

@@ -217,6 +217,11 @@ template <typename T> int launch_expand(const isls_expand_args &a, hipStream_t s
 template <typename T> int launch_linearize(const isls_linearize_args &a, hipStream_t s);
 template <typename T> int launch_accept(const isls_accept_args &a, hipStream_t s);
 template <typename T> int launch_advance(const isls_advance_args &a, hipStream_t s);
+// any (n <= 16, m <= 8) without an instantiation of the fast kernels: generic.hip (array form, one trajectory per wavefront)
+bool dims_generic(int n, int m);
+template <typename T> int launch_gain_generic(const isls_gain_args &a, hipStream_t s);
+template <typename T> int launch_ff_generic(const isls_ff_args &a, hipStream_t s);
+template <typename T> int launch_rollout_generic(const isls_rollout_args &a, hipStream_t s);
 template <typename T> int launch_reduce(int32_t B, const void *cost, const void *res, const int32_t *active,
                                         const int32_t *status, void *out5, hipStream_t s, int row = -1, int rows = 0);
 template <typename T> int launch_outer_begin(int32_t B, int32_t N, int32_t n, int32_t m, int32_t *admm_active,

@@ -43,6 +43,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 2 : 1)) void project_rows_ke
         sets[s].b = p.b[s] ? p.b[s] + (int64_t)pb * p.b_sp[s] : nullptr;
         sets[s].par = p.par[s] ? p.par[s] + (int64_t)pb * p.par_sp[s] : nullptr;
     }
+#ifndef ISLS_NO_SET_STAGE
+    __shared__ T set_lds[kMaxSets * kSetLdsWords];
+    stage_sets<T>(sets, p.nsets, D, set_lds);
+#endif
     int it = 0;
     if (p.algorithm == ISLS_PROJ_ALG_ADMM && p.nsets == 1 && sets[0].A == nullptr) {   // direct primitive
         T v[kMaxSetDim];
@@ -53,20 +57,25 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 2 : 1)) void project_rows_ke
         for (int j = 0; j < D; ++j) x[j] = v[j];
     } else {
         const int nw = (blockDim.x + 63) >> 6, wid = r >> 6;
-        // Workgroup-wide maxima once per inner iteration.  One wavefront (R <= 64): the butterfly's result is the answer, no
-        // LDS, no barrier.  Several: ONE barrier per call -- the partials alternate between two buffers, and a buffer is
-        // rewritten two calls later, behind the barrier of the call in between, which no thread passes before it has read it.
+        // Workgroup-wide maxima once per inner iteration: two barriers per call (-DISLS_ONE_BARRIER: alternating buffers, one
+        // barrier, none for a single wavefront -- measured slower, see sls_admm.hip).
         int par = 0;
         auto block_max = [&](T &a, T &b) {
             if (!row) { a = T(0); b = T(0); }
             a = wave_max(a);
             b = wave_max(b);
+#ifdef ISLS_ONE_BARRIER
             if (nw == 1) return;
+#endif
             if ((r & 63) == 0) { red[par][0][wid] = a; red[par][1][wid] = b; }
             __syncthreads();
             T ma = red[par][0][0], mb = red[par][1][0];
             for (int w = 1; w < nw; ++w) { ma = red[par][0][w] > ma ? red[par][0][w] : ma; mb = red[par][1][w] > mb ? red[par][1][w] : mb; }
+#ifndef ISLS_ONE_BARRIER                                           // default: second barrier (see the comment at `par`)
+            __syncthreads();
+#else
             par ^= 1;
+#endif
             a = ma;
             b = mb;
         };

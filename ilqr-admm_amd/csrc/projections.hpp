@@ -25,6 +25,57 @@ struct CSet {
     const T *A, *b, *par;          // this problem's A [dim,d], b [dim], parameters
 };
 
+// Words of a set's parameter block (include/isls_hip.h ISLS_SET_*): what stage_sets copies
+template <typename T>
+__device__ __forceinline__ int set_par_words(int kind, int dim, const T *par)
+{
+    switch (kind) {
+        case ISLS_SET_BOX: return 2 * dim;
+        case ISLS_SET_SQUARE: { const int q = (int)par[0]; return 3 + q + 2 * q * q; }
+        case ISLS_SET_LINEAR: return 2 + dim;
+        case ISLS_SET_QUADRATIC: return 2;
+        case ISLS_SET_SHELL: return 2 + dim;
+        case ISLS_SET_MULTILINEAR: { const int q = (int)par[0]; return 1 + 2 * q + q * dim; }
+        default: return 0;                                     // ISLS_SET_SOC_UNIT: no parameters
+    }
+}
+constexpr int kSetParMax = 3 + kMaxSetDim + 2 * kMaxSetDim * kMaxSetDim;                 // the keep-out square with q = dim
+constexpr int kSetLdsWords = kMaxSetDim * kMaxRowDim + kMaxSetDim + kSetParMax;           // A | b | par of one set
+
+// The sets of a problem are the same for all of its rows, and the inner iterations of project_set_convex read A_i, b_i and
+// the primitive's parameters again and again: from global memory that is an L2 round trip per element per iteration (rocprofv3:
+// the wavefronts of config 5 are parked on memory waits for 60 % of their life).  Every thread of the workgroup calls this once:
+// the operands are copied into LDS and the descriptors repointed there.  `lds` holds kMaxSets * kSetLdsWords words.
+template <typename T>
+__device__ __forceinline__ void stage_sets(CSet<T> (&sets)[kMaxSets], int nsets, int D, T *lds)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+#pragma unroll
+    for (int s = 0; s < kMaxSets; ++s) {
+        if (s < nsets) {
+            T *base = lds + s * kSetLdsWords;
+            const int dim = sets[s].dim;
+            if (sets[s].A) for (int e = tid; e < dim * D; e += nt) base[e] = sets[s].A[e];
+            if (sets[s].b) for (int e = tid; e < dim; e += nt) base[kMaxSetDim * kMaxRowDim + e] = sets[s].b[e];
+            if (sets[s].par) {
+                int np = set_par_words(sets[s].kind, dim, sets[s].par);
+                np = np < kSetParMax ? np : kSetParMax;
+                for (int e = tid; e < np; e += nt) base[kMaxSetDim * kMaxRowDim + kMaxSetDim + e] = sets[s].par[e];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kMaxSets; ++s) {
+        if (s < nsets) {
+            const T *base = lds + s * kSetLdsWords;
+            if (sets[s].A) sets[s].A = base;
+            if (sets[s].b) sets[s].b = base + kMaxSetDim * kMaxRowDim;
+            if (sets[s].par) sets[s].par = base + kMaxSetDim * kMaxRowDim + kMaxSetDim;
+        }
+    }
+}
+
 // numpy sign(): 0 for 0 (project_square_batch puts 0 on the arg-max entry of an all-zero row)
 template <typename T> __device__ __forceinline__ T np_sign(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0)); }
 

@@ -673,6 +673,7 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     if ((!a.Quu || !a.Qux || !a.fac) && (!a.rec || a.Quu || a.Qux || a.fac)) return ISLS_ERR_ARG;
     if (a.solve_mode != ISLS_SOLVE_CHOL && a.solve_mode != ISLS_SOLVE_INV) return ISLS_ERR_ARG;
     if (a.B == 0) return ISLS_OK;
+    if (!dims_supported(a.n, a.m)) return require_ff ? ISLS_OK : launch_gain_generic<T>(a, s);   // generic.hip (no ff pass inside)
     GainP<T> p;
     p.B = a.B; p.N = a.N; p.mode = a.solve_mode;
     p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.Cxx = View<T>(a.Cxx); p.Cuu = View<T>(a.Cuu); p.Cux = View<T>(a.Cux);
@@ -685,7 +686,7 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     const bool with_ff = ff && gain_ff_dims(a.n, a.m) && a.rec && ff->rec == a.rec && ff->k && ff->B == a.B && ff->N == a.N && ff->n == a.n && ff->m == a.m &&
                          ff->solve_mode == a.solve_mode && ff->active == a.active && ff->c0x.p && ff->c0u.p &&
                          (!ff->Qr.p || ff->Qr.st == 0) && (!ff->Rr.p || ff->Rr.st == 0) && (!ff->Qr.p || (ff->zx && ff->lx)) &&
-                         (!ff->Rr.p || (ff->zu && ff->lu)) && !a.Qux;
+                         (!ff->Rr.p || (ff->zu && ff->lu)) && !a.Qux && !ff->Qr_term && ff->_pad <= 1;
     if (require_ff && !with_ff) return ISLS_OK;
     if (with_ff) {
         p.c0x = View<T>(ff->c0x); p.c0u = View<T>(ff->c0u); p.Qr = View<T>(ff->Qr); p.Rr = View<T>(ff->Rr);

@@ -311,6 +311,8 @@ int launch_ff(const isls_ff_args &a, hipStream_t s)
     if ((int64_t)a.N * a.n * a.n * 64 >= ((int64_t)1 << 31) || a.A.sb * 64 >= ((int64_t)1 << 31) || a.Bm.sb * 64 >= ((int64_t)1 << 31))
         return ISLS_ERR_UNSUPPORTED;
     if (a.B == 0) return ISLS_OK;
+    if (!dims_supported(a.n, a.m)) return launch_ff_generic<T>(a, s);          // generic.hip
+    if ((a._pad > 1 || a.Qr_term) && !a.rec) return ISLS_ERR_UNSUPPORTED;     // feedback columns in one launch, terminal weight block: record path only
     if (a.rec) {                                               // packed records of the gain pass: riccati_ffrec.hip
         const bool sg = ff_seg_enabled(a.seg) && a.N > 2;
         if (sg && (a.seg.nseg > 16 || !a.seg.Psi || !a.seg.v || (int64_t)a.seg.nseg * a.seg.seg_len < a.N - 1 ||

@@ -41,6 +41,8 @@ struct FfRecP {
     T *k;
     const int32_t *active;
     int rev;                       // 1: the grid walks the trajectory blocks from the last to the first (see launch_ff_record)
+    const T *Qr_term;              // nullable: weight block of the terminal step (isls_ff_args.Qr_term), batch stride Qr.sb
+    int ncol;                      // feedback columns in one launch (blockIdx.z): zx, lx, zu, lu, k, vseg hold ncol blocks, c0 acts on column 0
 };
 
 // FG: ring entries are refilled in groups of FG consecutive steps -- one burst of FG records (FG x 648 B at n=6, m=3) per
@@ -280,6 +282,8 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     const int bb = valid ? b : bsh;                            // slots without a trajectory shadow the first valid one
     const int N = p.N;
     const int seg = blockIdx.y;
+    const int col = blockIdx.z;                                // feedback column (isls_admm): own targets and k, shared records
+    const T c0m = col == 0 ? T(1) : T(0);                      // the cost gradients belong to column 0
     const bool last = seg == p.nseg - 1;
     const int t_lo = seg * p.seg_len, t_hi = last ? N - 2 : t_lo + p.seg_len - 1;
     T *rec = lds + s * SLOT;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     const T *pc0 = xl ? p.c0x.at(bb, 0) + i : p.c0u.at(bb, 0) + iu;
     const int64_t c0st = xl ? p.c0x.st : p.c0u.st;
     const int dd = xl ? NX : NU;
-    const int64_t ovec = (int64_t)bb * N * dd + (xl ? i : iu);
+    const int64_t ovec = ((int64_t)col * p.B + bb) * N * dd + (xl ? i : iu);
     const T *phat = xl ? p.xhat : p.uhat;
     const bool hash = hasreg && phat != nullptr;
     const T *ph = hash ? phat + ovec : pc0;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     const int cbase = xl ? PHI_OFF + i : B_OFF + iu, cstr = xl ? NX : NU;   // own column of [Phi | B]
     const int ic = xl ? i : 0;
     const int ku = xl ? i % NU : iu;                           // the entry of k this lane stores (x-lanes: copies)
-    T *const kbase = p.k + (int64_t)bb * N * NU + ku;
+    T *const kbase = p.k + ((int64_t)col * p.B + bb) * N * NU + ku;
 
     // ---- terminal step: v = cx[N-1] (last segment; the others start from v_in = 0), qu = 0 -> k[t_hi + 1] ... -------------
     T vcur;
@@ -359,9 +363,10 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
         rec[d_dst] = dmask * (hmask * term.hv - (term.zv - term.lv));
         slot_sync();
         T sacc = T(0);
+        const T *qT = (p.Qr_term && xl) ? p.Qr_term + (int64_t)bb * p.Qr.sb + i * NX : nullptr;   // the terminal step's own weight row
 #pragma unroll
-        for (int j = 0; j < NX; ++j) sacc += qrow[j] * rrec[D_OFF + j];
-        const T cterm = term.c0 + sacc;                        // u-lanes: unused
+        for (int j = 0; j < NX; ++j) sacc += (qT ? T(2) * qT[j] : qrow[j]) * rrec[D_OFF + j];
+        const T cterm = c0m * term.c0 + sacc;                  // u-lanes: unused
         vcur = (last && xl) ? cterm : T(0);
         rec[o_dst] = xl ? vcur : T(0);                         // v, and qu = 0: the first k the loop emits is k[N-1] = 0 (last segment)
         slot_sync();
@@ -392,8 +397,8 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
 #pragma unroll
             for (int j = 0; j < JR; ++j) *reinterpret_cast<V2 *>(lds + dR[j]) = g.rr[j];
             rec[d_dst] = dmask * (hmask * g.hv - (g.zv - g.lv));
-            rec[c_dst] = g.c0;
-            const T c0_own = g.c0;
+            rec[c_dst] = c0m * g.c0;
+            const T c0_own = c0m * g.c0;
             slot_sync();
             fetch(t - D > t_lo ? t - D : t_lo, g);             // refill (clamped, unconditional)
             // ---- one batch of reads ----
@@ -495,7 +500,13 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
         for (int r = 1; r < NU; ++r) kv = (ku == r) ? kt[r] : kv;
         kbase[(int64_t)tprev * NU] = kv;
     }
-    if (seg > 0 && valid && xl) p.vseg[((int64_t)b * p.nseg + seg) * NX + i] = vcur;   // v0 at the segment start
+    if (seg > 0 && valid && xl) p.vseg[(((int64_t)col * p.B + b) * p.nseg + seg) * NX + i] = vcur;   // v0 at the segment start
+}
+
+static bool v2_on_()
+{
+    static const bool on = [] { const char *e = getenv("ISLS_FF_V2"); return !e || atoi(e) != 0; }();
+    return on;
 }
 
 template <typename T>
@@ -514,6 +525,10 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
     p.vseg = segmented ? (T *)a.seg.v : nullptr;
     const bool rowc = (!a.Qr.p || a.Qr.st == 0) && (!a.Rr.p || a.Rr.st == 0);
     // EXPERIMENT (ISLS_FF_REV = 1: every pass walks the blocks backwards; 2: consecutive passes alternate)
+    p.Qr_term = (const T *)a.Qr_term;
+    if (p.Qr_term && !(rowc && v2_on_() && a.Qr.p)) return ISLS_ERR_UNSUPPORTED;
+    p.ncol = a._pad > 1 ? a._pad : 1;
+    if (p.ncol > 1 && !(rowc && v2_on_())) return ISLS_ERR_UNSUPPORTED;   // columns ride on the one-hand-off kernel only
     static const int rev_mode = [] { const char *e = getenv("ISLS_FF_REV"); return e ? atoi(e) : 0; }();
     static int rev_count = 0;
     p.rev = rev_mode == 1 ? 1 : (rev_mode == 2 ? (rev_count++ & 1) : 0);
@@ -523,11 +538,11 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
 #ifndef ISLS_FF2_SEG_DEPTH
 #define ISLS_FF2_SEG_DEPTH 2
 #endif
-    static const bool v2_on = [] { const char *e = getenv("ISLS_FF_V2"); return !e || atoi(e) != 0; }();
+    const bool v2_on = v2_on_();
 #define LAUNCH2(NX_, NU_, MODE_)                                                                                        \
     {                                                                                                                   \
-        if (segmented) hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEG_DEPTH, (NX_ * NX_ > 64 ? 1 : 2), MODE_>), dim3(grid, p.nseg), dim3(64), 0, s, p); /* n = 9: 256 registers spill */ \
-        else hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEQ_DEPTH, 1, MODE_>), dim3(grid), dim3(64), 0, s, p);                 \
+        if (segmented) hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEG_DEPTH, (NX_ * NX_ > 64 ? 1 : 2), MODE_>), dim3(grid, p.nseg, p.ncol), dim3(64), 0, s, p); /* n = 9: 256 registers spill */ \
+        else hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEQ_DEPTH, 1, MODE_>), dim3(grid, 1, p.ncol), dim3(64), 0, s, p);      \
     }
 #define CALL(NX_, NU_)                                                                                                  \
     {                                                                                                                   \

@@ -32,6 +32,7 @@ int launch_rollout(const isls_rollout_args &a, hipStream_t s, const isls_admm_ar
     if (a.wq.p && (!a.zx || !a.lx)) return ISLS_ERR_ARG;
     if (a.wr.p && (!a.zu || !a.lu)) return ISLS_ERR_ARG;
     if (a.B == 0) return ISLS_OK;
+    if (!dims_supported(a.n, a.m)) return launch_rollout_generic<T>(a, s);     // generic.hip (no fused ADMM update: *did_fuse stays false)
     RoP<T> p;
     p.B = a.B; p.N = a.N; p.L = a.L; p.flags = a.flags;
     p.par = (const T *)a.model_par; p.par_sb = a.model_par_sb;

@@ -44,21 +44,32 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
         sets[s].b = p.b[s] ? p.b[s] + (int64_t)pb * p.b_sp[s] : nullptr;
         sets[s].par = p.par[s] ? p.par[s] + (int64_t)pb * p.par_sp[s] : nullptr;
     }
+#ifndef ISLS_NO_SET_STAGE
+    __shared__ T set_lds[kMaxSets * kSetLdsWords];
+    stage_sets<T>(sets, p.nsets, D, set_lds);
+#endif
     // workgroup-wide max (project_set_convex: once per inner iteration) and sum (residual norms); idle threads contribute
-    // zeros.  One wavefront (R <= 64, DI-1D): the butterfly is the answer -- no LDS, no barrier.  Several: ONE barrier per call:
-    // the partials alternate between two buffers, and a buffer is rewritten two calls later, behind the barrier of the call
-    // in between, which no thread passes before it has read it.
+    // zeros.  Two barriers per call (partials visible; buffer free again).  -DISLS_ONE_BARRIER builds the form with alternating
+    // buffers (one barrier per call, none for a one-wavefront problem): measured SLOWER on MI355X (config 5, B = 8192: DI-1D
+    // fp32 7505 vs 7794 it/s, DI-3D 3162 vs 3391; isls_admm's row projection 156 vs 150 us) -- the second barrier keeps the
+    // wavefronts of a workgroup in step through the set projections, whose loads then hit the same lines together.
     int par = 0;
     auto block_max = [&](T &a, T &b) {
         if (!row) { a = T(0); b = T(0); }
         a = wave_max(a);
         b = wave_max(b);
+#ifdef ISLS_ONE_BARRIER
         if (nw == 1) return;
+#endif
         if ((r & 63) == 0) { red[par][0][wid] = a; red[par][1][wid] = b; }
         __syncthreads();
         T ma = red[par][0][0], mb = red[par][1][0];
         for (int w = 1; w < nw; ++w) { ma = red[par][0][w] > ma ? red[par][0][w] : ma; mb = red[par][1][w] > mb ? red[par][1][w] : mb; }
+#ifndef ISLS_ONE_BARRIER
+        __syncthreads();
+#else
         par ^= 1;
+#endif
         a = ma;
         b = mb;
     };
@@ -66,12 +77,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
         if (!row) { a = T(0); b = T(0); }
         a = wave_sum(a);
         b = wave_sum(b);
+#ifdef ISLS_ONE_BARRIER
         if (nw == 1) return;
+#endif
         if ((r & 63) == 0) { red[par][0][wid] = a; red[par][1][wid] = b; }
         __syncthreads();
         T sa = T(0), sb = T(0);
         for (int w = 0; w < nw; ++w) { sa += red[par][0][w]; sb += red[par][1][w]; }
+#ifndef ISLS_ONE_BARRIER
+        __syncthreads();
+#else
         par ^= 1;
+#endif
         a = sa;
         b = sb;
     };
@@ -99,10 +116,23 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < D; ++c) x[c] = T(0);
-        for (int k = 0; k < R; ++k) {
-            const T l = p.Linv[(int64_t)k * R + rr_i];         // symmetric: column rr_i of row k, coalesced over the rows
+        // (the loads of a chunk are issued together: a wavefront is parked on these L2 round trips for most of its life --
+        // rocprofv3 SQ_WAIT_ANY 60 % of the wave cycles, profiles/r03_config5_pmc.json -- and one wait per element cost R of them)
+        constexpr int XC = 8;
+        for (int k0 = 0; k0 < R; k0 += XC) {
+            T l[XC];
 #pragma unroll
-            for (int c = 0; c < D; ++c) x[c] += l * rhs[k * D + c];
+            for (int q = 0; q < XC; ++q) {
+                const int k = k0 + q < R ? k0 + q : R - 1;     // clamped (surplus products are multiplied by zero)
+                l[q] = p.Linv[(int64_t)k * R + rr_i];          // symmetric: column rr_i of row k, coalesced over the rows
+            }
+#pragma unroll
+            for (int q = 0; q < XC; ++q) {
+                const int k = k0 + q < R ? k0 + q : R - 1;
+                const T lq = k0 + q < R ? l[q] : T(0);
+#pragma unroll
+                for (int c = 0; c < D; ++c) x[c] += lq * rhs[k * D + c];
+            }
         }
         __syncthreads();
         SLS_STAMP(cyc_x)

@@ -54,7 +54,7 @@ class FfArgs(C.Structure):
                 ("xhat", C.c_void_p), ("uhat", C.c_void_p),
                 ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
                 ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
-                ("k", C.c_void_p), ("active", C.c_void_p), ("seg", FfSeg), ("rec", C.c_void_p)]
+                ("k", C.c_void_p), ("active", C.c_void_p), ("seg", FfSeg), ("rec", C.c_void_p), ("Qr_term", C.c_void_p)]
 
 
 class FfPrepareArgs(C.Structure):
@@ -181,7 +181,7 @@ class AdvanceArgs(C.Structure):
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             ("riccati_gain", "riccati_ff", "riccati_gain_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
              "accept_step", "reduce_convergence", "reduce_convergence_table", "ilqr_admm_outer", "outer_advance")] + \
-           ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_dims_supported", "isls_error_string", "isls_timing_create",
+           ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_dims_supported", "isls_dims_generic", "isls_error_string", "isls_timing_create",
             "isls_timing_destroy", "isls_timing_reset", "isls_timing_pause", "isls_timing_read_ms"]
 
 
@@ -226,6 +226,15 @@ def dims_supported(n, m):
         _DIMS_LIB = load_hip_library()
         _DIMS_LIB.isls_dims_supported.restype = C.c_int32
     return bool(_DIMS_LIB.isls_dims_supported(C.c_int32(int(n)), C.c_int32(int(m))))
+
+
+def dims_generic(n, m):
+    """True when (n, m) is served at all: by the templated kernels or by the generic ones of csrc/generic.hip (n <= 16, m <= 8)."""
+    global _DIMS_LIB
+    if _DIMS_LIB is None:
+        _DIMS_LIB = load_hip_library()
+    _DIMS_LIB.isls_dims_generic.restype = C.c_int32
+    return bool(_DIMS_LIB.isls_dims_generic(C.c_int32(int(n)), C.c_int32(int(m))))
 
 
 def supported_dims(n_max=16, m_max=8):
@@ -368,9 +377,29 @@ class Kernels:
 
     @staticmethod
     def ff_args(A, Bm, c0x, c0u, K, Quu, fac, Qux, k, Qr=None, Rr=None, xhat=None, uhat=None,
-                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None, seg=None, rec=None):
+                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None, seg=None, rec=None, ncol=1, Qr_term=None):
         B, N, m, n = K.shape
-        a = FfArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode)
+        a = FfArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode, _pad=int(ncol) if ncol and ncol > 1 else 0)
+        if Qr_term is not None:                                 # weight block of the last step (isls_ff_args.Qr_term): [n,n]
+            if Qr is None or tuple(Qr.shape) not in ((n, n), (1, n, n), (1, 1, n, n)):
+                raise ValueError("Qr_term goes with a batch-shared, time-invariant Qr block")
+            a.Qr_term = _ptr(_dense(Qr_term, (n, n), "Qr_term"))
+        if ncol and ncol > 1:                                   # feedback columns: [C,B,N,.] blocks, checked as C*B trajectories
+            col = lambda t, d: None if t is None else _dense(t, (ncol, B, N, d), "column block").reshape(ncol * B, N, d)   # noqa: E731
+            zx, lx, zu, lu, k = col(zx, n), col(lx, n), col(zu, m), col(lu, m), col(k, m)
+            a.zx, a.lx, a.zu, a.lu, a.k = _ptr(zx), _ptr(lx), _ptr(zu), _ptr(lu), _ptr(k)
+            if Qr is not None and (zx is None or lx is None) or Rr is not None and (zu is None or lu is None):
+                raise ValueError("Qr / Rr given without z / l")
+            a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
+            a.c0x, a.c0u = make_view(c0x, B, N, (n,), "c0x"), make_view(c0u, B, N, (m,), "c0u")
+            a.Qr, a.Rr = make_view(Qr, B, N, (n, n), "Qr"), make_view(Rr, B, N, (m, m), "Rr")
+            a.xhat, a.uhat = _ptr(_dense(xhat, (B, N, n), "xhat")), _ptr(_dense(uhat, (B, N, m), "uhat"))
+            a.K = _ptr(_dense(K, (B, N, m, n), "K"))
+            a.active = _ptr(active)
+            a.rec = _ptr(_record(rec, B, N, n, m))
+            if seg is not None:
+                a.seg = seg
+            return a
         if seg is not None:
             a.seg = seg
         a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")

@@ -72,11 +72,12 @@ class Engine:
                                  "there is no CPU fallback")
         self.kern = kernels()
         self.B, self.N, self.n, self.m = int(batch), int(N), int(x_dim), int(u_dim)
-        if not capi.dims_supported(self.n, self.m):
-            # the kernels are templates over (x_dim, u_dim): fail here, not at the first kernel call
-            raise capi.IslsError(f"libisls_hip.so has no kernels for x_dim={self.n}, u_dim={self.m}; built pairs: "
-                                 f"{capi.supported_dims()} (one line per pair in csrc/isls_common.hpp, csrc/rollout.hip and "
-                                 f"csrc/Makefile adds another)")
+        # pairs with an instantiation of the row-per-lane kernels run those; any other pair with n <= 16, m <= 8 runs the generic
+        # kernels (csrc/generic.hip: array form, no packed records, no time-parallel segments); beyond that the library refuses
+        self.fast_dims = capi.dims_supported(self.n, self.m)
+        if not self.fast_dims and not capi.dims_generic(self.n, self.m):
+            raise capi.IslsError(f"libisls_hip.so has no kernels for x_dim={self.n}, u_dim={self.m}: the generic kernels serve "
+                                 f"x_dim <= 16, u_dim <= 8; instantiated fast pairs: {capi.supported_dims()}")
         self.dtype, self.device = dtype, torch.device(device)
         self.sfx = "f64" if dtype == torch.float64 else "f32"
         B, N, n, m = self.B, self.N, self.n, self.m
@@ -197,6 +198,13 @@ class Engine:
 
         has_x, has_u = x_box is not None or x_sets is not None, u_box is not None or u_sets is not None
         self.Qr = weights(rho_x, n) if has_x else None
+        # a state weight that is the same at every step but the LAST (a terminal constraint: the arm notebook's bound on the
+        # final end-effector position) reaches the record feed-forward passes as one block plus the terminal block
+        # (isls_ff_args.Qr_term): they then run the one-hand-off kernel instead of loading a weight row per step
+        self.Qr_ff, self.Qr_term = None, None
+        if (self.Qr is not None and self.Qr.ndim == 3 and self.Qr.shape[0] == N and N > 2 and bool((self.Qr[:-1] == self.Qr[:1]).all())
+                and os.environ.get("ISLS_FF_QR_TERM", "1") != "0"):
+            self.Qr_ff, self.Qr_term = self.Qr[:1].contiguous(), self.Qr[-1].contiguous()
         self.Rr = weights(rho_u, m) if has_u else None
         if has_x and self.Qr is None:
             raise ValueError("project_x needs rho_x")
@@ -290,7 +298,7 @@ class Engine:
         """Packed step records [A + B K | B | K | fac] the gain pass writes for the feed-forward passes (isls_gain_args.rec /
         isls_ff_args.rec), or None when switched off (ISLS_FF_RECORD=0).  Only the drivers that run the gain pass
         themselves right before the feed-forward passes use it: the records are stale once K / fac are replaced."""
-        if os.environ.get("ISLS_FF_RECORD", "1") == "0":
+        if os.environ.get("ISLS_FF_RECORD", "1") == "0" or not self.fast_dims:
             return None
         if getattr(self, "_ffrec", None) is None:
             self._ffrec = torch.zeros(capi.ff_record_elems(self.B, self.N, self.n, self.m), dtype=self.dtype, device=self.device)
@@ -305,9 +313,17 @@ class Engine:
                                Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active, rec=rec,
                                stream=_stream_ptr())
 
+    def _ff_weights(self, rec):
+        """(Qr, Qr_term) operands of a feed-forward pass: the terminal-block form on the packed records when it applies"""
+        rr_inv = self.Rr is None or self.Rr.ndim < 3 or self.Rr.shape[-3] == 1
+        if rec is not None and getattr(self, "Qr_term", None) is not None and rr_inv and os.environ.get("ISLS_FF_V2", "1") != "0":
+            return self.Qr_ff, self.Qr_term
+        return self.Qr, None
+
     def feedforward(self, active=None, seg=None, rec=None):
+        Qr, Qr_term = self._ff_weights(rec)
         self.kern.riccati_ff(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
-                             Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx,
+                             Qr=Qr, Qr_term=Qr_term, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx,
                              zu=self.zu, lu=self.lu, solve_mode=self.solve_mode, active=active, seg=seg, rec=rec,
                              stream=_stream_ptr())
 
@@ -329,6 +345,8 @@ class Engine:
     # ---- time-parallel feed-forward pass (isls_ffseg): operators from the gain pass, reused by J ADMM iterations
     def ff_seg(self, nseg_requested=None):
         """Segment descriptor over engine-owned buffers, or None for the sequential recursion."""
+        if not self.fast_dims:
+            return None                                        # the generic kernels recurse sequentially
         if nseg_requested is None:
             # measured on MI355X (DESIGN.md 5): from ~2k trajectories on the pass is bound by HBM throughput whatever its
             # shape (82-87 us for 1, 2 or 3 segments at B=4096; 45 / 36+29 / 39+26 us pass+prepare at B=2048), so the
@@ -359,8 +377,9 @@ class Engine:
         gain = K.gain_args(self.A, self.Bm, *self.hessians(), self.K, self.Quu if full else None, self.fac if full else None,
                            self.Qux if full else None, Cux=self.Cux, solve_mode=self.solve_mode, status=self.status,
                            active=self.admm_active, rec=rec)
+        Qr_ff, Qr_term = self._ff_weights(rec)
         ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
-                       Qr=self.Qr, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
+                       Qr=Qr_ff, Qr_term=Qr_term, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
                        lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=self.ff_seg(ff_nseg), rec=rec)
         ro = K.rollout_args(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
                             self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,

@@ -70,8 +70,15 @@ class ColumnSolver:
         self.rec = e.ff_record()
         e.gain(active=active, rec=self.rec)
         self.seg = e.ff_seg()
+        self.seg_cols = None
         if self.seg is not None:
             e.feedforward_prepare(self.seg, active=active, rec=self.rec)
+            # the same operators with a segment-start scratch per column ([C,B,nseg,n]) for the one-launch form
+            G, Psi, v = e._seg_bufs
+            if getattr(self, "_vcols", None) is None or self._vcols.shape[2] != v.shape[1]:
+                self._vcols = torch.zeros(self.C, *v.shape, dtype=e.dtype, device=e.device)
+            self.seg_cols = capi.Kernels.ff_seg(G, Psi, self._vcols.view(self.C * v.shape[0], *v.shape[1:])[:v.shape[0]], self.seg.seg_len)
+            self.seg_cols.v = self._vcols.data_ptr()
         self.Cuu = e.hessians()[1]
 
     def restart(self, active):
@@ -84,6 +91,14 @@ class ColumnSolver:
             if blk is not None:
                 blk["l"].zero_()
 
+    def _columns_in_one_launch(self):
+        """The C passes ride in one launch on the packed records when the ADMM weights do not depend on the time step (the
+        one-hand-off kernel's condition); ISLS_ADMM_FF_COLUMNS=0 keeps one launch per column."""
+        e = self.e
+        inv = lambda W: W is None or W.ndim < 3 or W.shape[-3] == 1                      # noqa: E731
+        return (self.rec is not None and inv(e.Qr) and inv(e.Rr) and os.environ.get("ISLS_ADMM_FF_COLUMNS", "1") != "0"
+                and os.environ.get("ISLS_FF_V2", "1") != "0")
+
     def x_step(self):
         """[d_x, phi_x], [d_u, phi_u] for the targets z - lmb: C feed-forward passes, then the column rollout.  A weight that
         is set without a projected block pulls towards zero (its target is the zero vector), as in the reference, where
@@ -93,15 +108,28 @@ class ColumnSolver:
         if not hasattr(self, "_zero_zx"):
             zz = lambda d: torch.zeros(e.B, e.N, d, dtype=e.dtype, device=e.device)       # noqa: E731
             self._zero_zx, self._zero_zu = zz(e.n), zz(e.m)
-        for c in range(self.C):
-            zx, lx = (bx["z"][c], bx["l"][c]) if bx is not None else (self._zero_zx, self._zero_zx)
-            zu, lu = (bu["z"][c], bu["l"][c]) if bu is not None else (self._zero_zu, self._zero_zu)
+            zc = lambda d: torch.zeros(self.C, e.B, e.N, d, dtype=e.dtype, device=e.device)   # noqa: E731
+            self._zero_cx, self._zero_cu = (zc(e.n) if bx is None else None), (zc(e.m) if bu is None else None)
+        ff_kw = dict(Qr=e.Qr, Rr=e.Rr, solve_mode=e.solve_mode, active=act, rec=self.rec, stream=_stream_ptr())
+        if self._columns_in_one_launch():
+            # all C feed-forward passes as ONE launch (isls_ff_args ncol): the columns share the packed records, each has its
+            # own targets z - lmb and its own k; the cost gradients act on column 0
+            zx, lx = (bx["z"], bx["l"]) if bx is not None else (self._zero_cx, self._zero_cx)
+            zu, lu = (bu["z"], bu["l"]) if bu is not None else (self._zero_cu, self._zero_cu)
             with e.timed("riccati_ff"):
-                e.kern.riccati_ff(e.A, e.Bm, e.c0x if c == 0 else self.zero_x, e.c0u if c == 0 else self.zero_u, e.K, e.Quu,
-                                  e.fac, e.Qux, self.kcol[c], Qr=e.Qr, Rr=e.Rr, zx=zx if e.Qr is not None else None,
-                                  lx=lx if e.Qr is not None else None, zu=zu if e.Rr is not None else None,
-                                  lu=lu if e.Rr is not None else None, solve_mode=e.solve_mode, active=act, seg=self.seg,
-                                  rec=self.rec, stream=_stream_ptr())
+                e.kern.riccati_ff(e.A, e.Bm, e.c0x, e.c0u, e.K, e.Quu, e.fac, e.Qux, self.kcol,
+                                  zx=zx if e.Qr is not None else None, lx=lx if e.Qr is not None else None,
+                                  zu=zu if e.Rr is not None else None, lu=lu if e.Rr is not None else None,
+                                  seg=self.seg_cols, ncol=self.C, **ff_kw)
+        else:
+            for c in range(self.C):
+                zx, lx = (bx["z"][c], bx["l"][c]) if bx is not None else (self._zero_zx, self._zero_zx)
+                zu, lu = (bu["z"][c], bu["l"][c]) if bu is not None else (self._zero_zu, self._zero_zu)
+                with e.timed("riccati_ff"):
+                    e.kern.riccati_ff(e.A, e.Bm, e.c0x if c == 0 else self.zero_x, e.c0u if c == 0 else self.zero_u, e.K, e.Quu,
+                                      e.fac, e.Qux, self.kcol[c], zx=zx if e.Qr is not None else None,
+                                      lx=lx if e.Qr is not None else None, zu=zu if e.Rr is not None else None,
+                                      lu=lu if e.Rr is not None else None, seg=self.seg, **ff_kw)
         with e.timed("columns_rollout"):
             e.kern.columns_rollout(e.A, e.Bm, self.Cuu, e.c0u, e.K, self.kcol, self.dx, self.du,
                                    Rr=e.Rr if bu is not None else None, zu=bu["z"] if bu is not None else None,

@@ -106,6 +106,24 @@ def config2(batch, N=100, seed=0):
                 relax=1.0, model=MODEL_LTI)
 
 
+def config_generic(n, m, batch, N=40, seed=0):
+    """A seeded LTI problem of ANY state / control dimension (the reference takes any, isls/base.py:11-14): a lightly coupled,
+    marginally stable A = I + dt * G, B = dt * H, a terminal via-point, a box on u -- the shape of config 2 for pairs (n, m)
+    the double integrators do not produce."""
+    rng = np.random.default_rng(seed + 1000 * n + m)
+    dt = 0.05
+    A = np.eye(n) + dt * (rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n))
+    B = dt * rng.standard_normal((n, m))
+    x0 = rng.uniform(-0.5, 0.5, size=(batch, n))
+    zs = np.zeros((batch, 2, n))
+    zs[:, 1] = rng.uniform(0.5, 1.5, size=(batch, n))
+    Qs = np.stack([np.zeros((n, n)), 1e2 * np.eye(n)])
+    seq = np.zeros(N, dtype=np.int32)
+    seq[N - 1] = 1
+    return dict(name=f"lti_{n}_{m}", n=n, m=m, N=N, dt=dt, A=A, B=B, zs=zs, Qs=Qs, seq=seq, u_std=1e-2, x0=x0,
+                u0=np.zeros((batch, N, m)), u_lo=-2.0, u_hi=2.0, rho_u=5e-2, relax=1.0, model=MODEL_LTI)
+
+
 # --------------------------------------------------------------------------------------------
 # Planar 3R arm, state s=[q(3), qd(3), ee(3)], u=qdd
 # --------------------------------------------------------------------------------------------

@@ -23,9 +23,9 @@
  *   - `active` (nullable) : trajectories with active[b]==0 are skipped entirely (frozen: converged
  *     or failed, SURVEY section 5 "failure detection").
  *
- * Supported (n,m): {2,1} {4,2} {6,3} {9,3} (the reference notebooks' systems) and {3,1} {6,2} {2,2} {3,3} (with them every
- * get_double_integrator_AB(nb_dim <= 3, nb_deriv <= 3) system); isls_dims_supported(n, m) answers for a pair, others ->
- * ISLS_ERR_UNSUPPORTED.  1 <= L <= 64.
+ * (n,m) with fast (templated) kernels: {2,1} {4,2} {6,3} {9,3} (the reference notebooks' systems) and {3,1} {6,2} {2,2} {3,3} (with
+ * them every get_double_integrator_AB(nb_dim <= 3, nb_deriv <= 3) system): isls_dims_supported(n, m).  Every other pair with
+ * n <= 16, m <= 8 runs the generic kernels (isls_dims_generic); beyond that ISLS_ERR_UNSUPPORTED.  1 <= L <= 64.
  */
 #ifndef ISLS_HIP_H
 #define ISLS_HIP_H
@@ -162,7 +162,10 @@ int32_t isls_ff_segments(int32_t N, int32_t nseg_requested, int32_t *seg_len);
 typedef struct isls_ff_args {
     int32_t B, N, n, m;
     int32_t solve_mode;
-    int32_t _pad;
+    int32_t _pad;                   /* ncol: 0 / 1 = one pass.  C > 1: the C feedback columns of isls_admm (isls/isls.py:578-590) in ONE
+                                     * launch on the same records: zx, lx, zu, lu and k hold C blocks [C,B,N,.], seg.v holds [C,B,nseg,n],
+                                     * c0x / c0u act on column 0 only (the other columns carry no cost gradient).  Record path with
+                                     * time-invariant Qr / Rr only (else ISLS_ERR_UNSUPPORTED: call once per column) */
     isls_view A, Bm;
     isls_view c0x; /* [.,.,n] */
     isls_view c0u; /* [.,.,m] */
@@ -178,6 +181,11 @@ typedef struct isls_ff_args {
                                      * reads them instead of A, Bm, K, Quu, fac, Qux and evaluates the same recursion as
                                      * v = cx + K'cu + (A + B K)'v, k = -Quu^-1 (cu + B'v): one contiguous 81-word burst per
                                      * step instead of 108 words in six streams (n=6, m=3); results equal up to rounding */
+    const void *Qr_term;            /* nullable: the state weight block [n,n] of the LAST step (batch stride Qr.sb), replacing Qr
+                                     * there -- a weight that is the same at every step but the terminal one (a terminal state
+                                     * constraint: notebooks/3DoF robot/State and control bound constraints.ipynb cell 22) is
+                                     * then passed with a zero time stride and keeps the one-hand-off record kernel.  Record
+                                     * path with time-invariant Qr / Rr only (else ISLS_ERR_UNSUPPORTED: pass the full [N,n,n]) */
 } isls_ff_args;
 
 int isls_riccati_ff_f64(const isls_ff_args *a, void *stream);
@@ -613,6 +621,12 @@ int isls_version(void);
 /* 1 when the kernels are instantiated for state dimension n and control dimension m (the pairs are compile-time template
  * arguments: csrc/isls_common.hpp ISLS_FOR_EACH_DIMS), else 0: every entry point returns ISLS_ERR_UNSUPPORTED for other pairs. */
 int32_t isls_dims_supported(int32_t n, int32_t m);
+/* 1 when (n, m) is served at all: every pair with n <= 16, m <= 8 (the reference takes any dimensions, isls/base.py:11-14).  Pairs
+ * without an instantiation run the generic kernels (csrc/generic.hip: dimensions at run time, one trajectory per wavefront,
+ * matrices in LDS; array form only -- no packed records, no time-parallel segments, dense LTI / double-integrator model,
+ * via-point cost): isls_riccati_gain / isls_riccati_ff / isls_rollout_ls / isls_admm_update / isls_ilqr_admm_outer and the
+ * streaming kernels work, the isls_columns_* entry points of isls_admm do not (ISLS_ERR_UNSUPPORTED). */
+int32_t isls_dims_generic(int32_t n, int32_t m);
 const char *isls_error_string(int code);
 /* Per-kernel-family durations for bench.py: HIP events recorded on the launch stream around the launches that
  * isls_ilqr_admm_outer_* enqueues, kept in a CALLER-OWNED context (the library itself has no state): create one, put it

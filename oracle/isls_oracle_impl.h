@@ -195,7 +195,7 @@ static void FN(reg_grad)(const isls_ff_args *a, int b, int t, REAL *cx, REAL *cu
     for (int i = 0; i < n; ++i) cx[i] = c0x[i];
     for (int i = 0; i < m; ++i) cu[i] = c0u[i];
     if (a->Qr.p) {
-        const REAL *Qr = VIEW(a->Qr, b, t);
+        const REAL *Qr = (a->Qr_term && t == N - 1) ? (const REAL *)a->Qr_term + (int64_t)b * a->Qr.sb : VIEW(a->Qr, b, t);
         const REAL *xh = a->xhat ? (const REAL *)a->xhat + ((int64_t)b * N + t) * n : 0;
         const REAL *z = (const REAL *)a->zx + ((int64_t)b * N + t) * n, *l = (const REAL *)a->lx + ((int64_t)b * N + t) * n;
         REAL d[MAXN];

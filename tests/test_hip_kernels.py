@@ -620,7 +620,35 @@ def test_further_state_control_dimensions(dual, nb_dim, nb_deriv):
         d = OracleDriver(dk, pa, rho_x=0.05, rho_u=cfg["rho_u"], project_x=True)
         d.run(2, 12, 3, 0.0)
         _report(dk)
-    assert not capi.dims_supported(5, 7)
+    assert not capi.dims_supported(5, 7) and capi.dims_generic(5, 7) and not capi.dims_generic(17, 2) and not capi.dims_generic(4, 9)
+
+
+@pytest.mark.parametrize("n,m,dtype,tol", [(5, 2, "f64", 1e-10), (8, 4, "f64", 1e-10), (12, 6, "f64", 1e-10), (16, 8, "f64", 1e-10),
+                                           (1, 1, "f64", 1e-10), (7, 3, "f32", 1e-4), (5, 7, "f32", 1e-4)])
+def test_any_state_and_control_dimension(dual, oracle, n, m, dtype, tol):
+    """(x_dim, u_dim) WITHOUT an instantiation of the row-per-lane kernels (the reference takes any dimensions,
+    isls/base.py:11-14): the generic kernels of csrc/generic.hip (dimensions at run time, matrices in LDS, one trajectory per
+    wavefront) against the oracle, kernel call by kernel call over two outer iterations of the DP-form iLQR-ADMM (gain,
+    feed-forward, line search with 9 candidates, box update on u and on half of the states) and both solve modes of the gain /
+    feed-forward pair (the class surface and the C driver: tests/test_isls_api.py::test_any_dimension_through_the_class_surface)."""
+    from helpers import rho_to_weights
+    assert not capi.dims_supported(n, m) and capi.dims_generic(n, m)
+    f = np.float64 if dtype == "f64" else np.float32
+    cfg = P.config_generic(n, m, batch=6, N=40, seed=1)
+    pa = problem_arrays(cfg, range(5), dtype=f)
+    pa["x_lo"] = np.full((40, n), -np.inf, dtype=f); pa["x_hi"] = np.full((40, n), np.inf, dtype=f)
+    pa["x_lo"][:, : (n + 1) // 2], pa["x_hi"][:, : (n + 1) // 2] = -1.0, 1.6
+    dk = dual(tol=tol)
+    dk.int_exact = dtype == "f64"
+    d = OracleDriver(dk, pa, rho_x=0.05, rho_u=cfg["rho_u"], project_x=True, relax=1.2, dtype=f)
+    d.run(2, 9, 3, 0.0)
+    # explicit-inverse mode of the SLS path (isls/sls.py:149-151) on the same operands
+    d.linearize_expand()
+    for mode in (capi.SOLVE_CHOL, capi.SOLVE_INV):
+        dk.riccati_gain(d.A, d.Bm, d.Cxx, d.Cuu, d.K, d.Quu, d.fac, d.Qux, solve_mode=mode, status=d.status, active=d.admm_active)
+        dk.riccati_ff(d.A, d.Bm, d.c0x, d.c0u, d.K, d.Quu, d.fac, d.Qux, d.k, Qr=d.Qr, Rr=d.Rr, xhat=d.xhat, uhat=d.uhat, zx=d.zx, lx=d.lx,
+                      zu=d.zu, lu=d.lu, solve_mode=mode, active=d.admm_active)
+    _report(dk)
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5])

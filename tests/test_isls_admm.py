@@ -277,6 +277,26 @@ def test_isls_admm_host_get_AB_with_recorded_iteration(golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nseg", ["1", "4"])
+def test_feedback_columns_in_one_launch_equal_one_launch_per_column(golden, monkeypatch, nseg):
+    """isls_ff_args ncol: the C = 1 + dim feed-forward passes of an ADMM iteration as ONE launch on the shared records
+    (blockIdx.z = column; sequential and time-parallel form) against one launch per column: the same kernel on the same
+    operands, so every output is bit-identical."""
+    g = golden("g9_isls_admm.npz")
+    cfg, cs = arm_cfg(), control_sets(g)
+    kw = dict(max_line_search=30, k_max=2, project_u=cs, rho_u=1.0, max_admm_iter=4, threshold=0.0)
+    monkeypatch.setenv("ISLS_FF_NSEG", nseg)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ISLS_ADMM_FF_COLUMNS", mode)
+        s = make_arm(cfg, [0, 1])
+        du, phi = s.isls_admm(3, None, **kw)
+        out[mode] = (du, phi, np.array(s.x_nom), np.array(s.u_nom), np.array(s.cost_log), s.admm_logs)
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_isls_admm_callable_projection_equals_device_sets(oracle, golden):
     """project_u given as the notebook's numpy closure (host round trip) runs the same iteration as the ConvexSets route."""
     g = golden("g9_isls_admm.npz")

@@ -440,6 +440,25 @@ def test_ilqr_admm_host_projection_path(golden):
     assert rel(s.x_nom, d.x_nom) < 1e-12 and rel(s.u_nom, d.u_nom) < 1e-12
 
 
+@pytest.mark.parametrize("n,m", [(5, 2), (12, 6)])
+def test_any_dimension_through_the_class_surface(oracle, n, m):
+    """iSLS with a state / control dimension that has no instantiation of the fast kernels (the reference takes any,
+    isls/base.py:11-14): `solve` (plain DP iLQR) and `ilqr_admm` (box on u) run on the generic kernels through the same class
+    surface and the C driver, and reproduce the oracle's outer loop on the same problem (nominal, cost log, K)."""
+    from helpers import OracleDriver, problem_arrays
+    from isls import Box
+    cfg = P.config_generic(n, m, batch=4, N=40, seed=2)
+    s = make_isls(cfg, [0, 1, 2])
+    assert not s.engine.fast_dims and s.engine.ff_record() is None
+    s.ilqr_admm(project_u=Box(cfg["u_lo"], cfg["u_hi"]), max_iter=2, max_line_search_iter=9, max_admm_iter=3, rho_u=cfg["rho_u"],
+                alpha=cfg["relax"], tol=0.0)
+    d = OracleDriver(oracle, problem_arrays(cfg, range(3)), rho_u=cfg["rho_u"], relax=cfg["relax"])
+    d.run(2, 9, 3, 0.0)
+    assert rel(s.x_nom, d.xhat) < TOL and rel(s.u_nom, d.uhat) < TOL and rel(s.K, d.K) < TOL
+    assert rel(np.array(s.cost_log)[-1], d.cost) < TOL
+    assert (s.status == 0).all()
+
+
 def test_unbuilt_paths_fail_loudly():
     import isls
     s = isls.iSLS(6, 3, 20)

@@ -114,4 +114,6 @@ def test_bench_two_rank_rehearsal():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["convergence"]["active"] == 600.0 and out["convergence"]["failed"] == 0.0
-    assert out["value"] > 0 and "cpu_baseline" not in out
+    # same keys as the N = 1 line: the CPU baseline is timed at N = 1 only and is null here; the collective layer reports what it saw
+    assert out["value"] > 0 and out["cpu_baseline"] is None
+    assert out["n_ranks_joined"] == 2 and out["collective_backend"] == "gloo"

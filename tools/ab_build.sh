@@ -9,7 +9,7 @@ out=$root/ab/$name
 mkdir -p "$out"
 cd "$root/ilqr-admm_amd/csrc"
 FL="-O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-variable -Wno-unused-but-set-variable -Wno-unused-value $*"
-SRCS="riccati riccati_ff riccati_ffrec ff_segments rollout admm project sls_admm feedback_columns misc capi"
+SRCS="riccati riccati_ff riccati_ffrec ff_segments rollout admm project sls_admm feedback_columns misc generic capi"
 FAMS="4_2_0 4_2_2 4_2_3 4_2_4 9_3_0 9_3_1 6_3_0 6_3_3 2_1_0 2_1_3 3_1_0 6_2_0 2_2_0 3_3_0"
 pids=()
 throttle() { if (( ${#pids[@]} >= 5 )); then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi; }
