@@ -42,10 +42,13 @@ __device__ __forceinline__ int set_par_words(int kind, int dim, const T *par)
 constexpr int kSetParMax = 3 + kMaxSetDim + 2 * kMaxSetDim * kMaxSetDim;                 // the keep-out square with q = dim
 constexpr int kSetLdsWords = kMaxSetDim * kMaxRowDim + kMaxSetDim + kSetParMax;           // A | b | par of one set
 
-// The sets of a problem are the same for all of its rows, and the inner iterations of project_set_convex read A_i, b_i and
-// the primitive's parameters again and again: from global memory that is an L2 round trip per element per iteration (rocprofv3:
-// the wavefronts of config 5 are parked on memory waits for 60 % of their life).  Every thread of the workgroup calls this once:
-// the operands are copied into LDS and the descriptors repointed there.  `lds` holds kMaxSets * kSetLdsWords words.
+// EXPERIMENT (-DISLS_SET_STAGE), measured and NOT adopted.  The sets of a problem are the same for all of its rows, and the inner
+// iterations of project_set_convex read A_i, b_i and the primitive's parameters again and again from global memory (L2 hits;
+// rocprofv3: the wavefronts of config 5 are parked on waits for 60 % of their life).  Copying them into LDS and repointing the
+// descriptors there turns those reads into FLAT loads (the descriptors hold generic pointers), and those ran slower than the
+// L2 hits they replace: config 5 DI-1D fp32 7100 vs 7729 it/s, DI-3D 2751 vs 3246; config 4's row projection 197 vs 141 us,
+// isls_admm's 98 vs 62 us.  A form that would pay needs the descriptors typed as LDS (ds_read), i.e. the set loops templated
+// on the address space.  `lds` holds kMaxSets * kSetLdsWords words.
 template <typename T>
 __device__ __forceinline__ void stage_sets(CSet<T> (&sets)[kMaxSets], int nsets, int D, T *lds)
 {

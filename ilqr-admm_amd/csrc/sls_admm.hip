@@ -44,7 +44,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
         sets[s].b = p.b[s] ? p.b[s] + (int64_t)pb * p.b_sp[s] : nullptr;
         sets[s].par = p.par[s] ? p.par[s] + (int64_t)pb * p.par_sp[s] : nullptr;
     }
-#ifndef ISLS_NO_SET_STAGE
+#ifdef ISLS_SET_STAGE                                              // experiment, off: measured slower (see stage_sets in projections.hpp)
     __shared__ T set_lds[kMaxSets * kSetLdsWords];
     stage_sets<T>(sets, p.nsets, D, set_lds);
 #endif

@@ -265,7 +265,12 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
               cs.rec, cs.Cuu] + (list(e._seg_bufs) if getattr(e, "_seg_bufs", None) is not None and cs.seg is not None else [])
         return tuple(None if t is None else t.data_ptr() for t in ts)
 
-    for k in range(k_max):
+    mark = getattr(self, "_bench_mark", None)                                   # bench.py: wall clock of the outer iterations after
+    for k in range(k_max):                                                      # the first (which records the HIP graph)
+        if mark is not None and k == 1:
+            import time
+            torch.cuda.synchronize()
+            mark["t1"] = time.perf_counter()
         outer_count.add_(e.outer_active)
         self._linearize(get_AB)
         self._expand_regularised(get_Cs)                                        # built-in cost on the device, else the caller's get_Cs (isls.py:548-560)

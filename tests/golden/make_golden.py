@@ -1074,6 +1074,12 @@ def gen_noise():
     np.random.seed(126)
     out["arm_K"] = Kz
     out["arm_dp_x"], out["arm_dp_u"] = isl.get_trajectory_dp(x0, Kz, kz, noise_scale=0.01)
+    # a BATCH of initial states (2-D x0): the reference's iSLS returns only trajectory 0 of the batch (the `x0.ndim == 2` test of
+    # isls_base.py:39-42,68-71 is inverted); the noise is still drawn for all of them, so row 0 pins the batched loop
+    x0s2 = x0[None] + np.random.default_rng(8).normal(scale=0.05, size=(3, 9))
+    np.random.seed(127)
+    out["arm_x0s2"] = x0s2
+    out["arm_dp2_x0"], out["arm_dp2_u0"] = isl.get_trajectory_dp(x0s2, Kz, kz, noise_scale=0.01)
     save("g13_noise.npz", **out)
 
 

@@ -131,3 +131,9 @@ def test_process_noise_reproduces_the_seeded_reference(golden):
     np.random.seed(126)
     x, u = arm.get_trajectory_dp(g["arm_x0"], g["arm_K"], g["arm_us"], noise_scale=0.01)
     assert rel(x, g["arm_dp_x"]) < 1e-12 and rel(u, g["arm_dp_u"]) < 1e-12
+    # a batch of initial states: the reference's iSLS keeps trajectory 0 only (inverted `x0.ndim` test, isls_base.py:39-42,
+    # 68-71), this package returns the whole batch (documented deviation); row 0 is the reference's
+    np.random.seed(127)
+    x, u = arm.get_trajectory_dp(g["arm_x0s2"], g["arm_K"], g["arm_us"], noise_scale=0.01)
+    assert x.shape == (3, 100, 9) and u.shape == (3, 100, 3)
+    assert rel(x[0], g["arm_dp2_x0"]) < 1e-12 and rel(u[0], g["arm_dp2_u0"]) < 1e-12
