@@ -550,6 +550,15 @@ def config5_run(kern, Linv, r_side, rr, cs, iters, dtype, wrap, sync, gpu_events
     return wall, x_u, kernel_ms
 
 
+def config5_counters(dim, dtype_name, D):
+    """Fractions of the wave cycles of sls_admm_kernel from the committed rocprofv3 SQ / TCC passes (tools/pmc_config5.sh)."""
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", "r03_config5_pmc.json")))["kernels"]
+        return k.get(f"d{dim} isls::sls_admm_kernel<{'float' if dtype_name == 'f32' else 'double'}, {D}, 256>")
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def config5_main(args):
     """`bench.py --config5`: config 5 of BASELINE.json / SURVEY 8(d) -- SLS-ADMM with SOC chance constraints, N=50, B=8192
     problems that differ in target, bound and variance, fp32 and fp64.  One JSON line per precision: ADMM iterations/s over
@@ -576,14 +585,18 @@ def config5_main(args):
                "config": {"workload": f"config5: DI-{args.config5_dim}D SLS-ADMM, SOC chance constraints", "batch": B, "horizon": N,
                           "admm_iters": iters, "inner_max_iter": cs.max_iter},
                "problems_per_s": B / dt, "ms_per_solve": 1e3 * dt,
-               "roofline": {"bound": "mfma", "kernel": "sls_admm_kernel", "avg_launch_ms": kms,
+               "roofline": {"bound": "latency", "kernel": "sls_admm_kernel", "avg_launch_ms": kms,
+                            "limiter": "L2 round trips on every row's dependent chain: rocprofv3 SQ counters of this kernel (committed "
+                                       "profile below) show the wavefronts parked in s_waitcnt / s_barrier for most of their cycles, the vector "
+                                       "ALU active for a fifth, the LDS for 1-3 %, HBM idle (39 MB per batch solve); neither the HBM nor a matrix roof applies",
                             "achieved": flops / (kms * 1e-3) / 1e12, "peak": vec_peak, "unit": "TFLOP/s",
                             "frac": flops / (kms * 1e-3) / 1e12 / vec_peak, "traffic": None,
+                            "counters": config5_counters(args.config5_dim, name, D_), "pmc_profile": "r03_config5_pmc.json",
                             "algorithmic_flops_per_launch": flops,
                             "algorithmic_bytes_per_launch": 2.0 * B * R_ * D_ * w,
                             "hbm_achieved_GBs": 2.0 * B * R_ * D_ * w / (kms * 1e-3) / 1e9,
-                            "note": "x-step flops only; cycle stamps (DESIGN 5b): the x-step is 4 % (DI-1D) / 28 % (DI-3D) of "
-                                    "the kernel, the rest is the per-row set projection"}}
+                            "note": "`achieved` / `frac` count the x-step's multiply-adds only, against the vector peak (fp32 MFMA runs at the "
+                                    "vector rate on gfx950): a figure of merit, not the bound"}}
         if not args.no_cpu_baseline:                             # the CPU oracle, a reported baseline only
             from oracle import oracle as orc
             okern, olib = orc.load()

@@ -206,6 +206,14 @@ ISLS_API int isls_columns_admm_f32(const isls_columns_admm_args *a, void *stream
 {
     return a ? launch_columns_admm<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
 }
+ISLS_API int isls_columns_iteration_f64(const isls_columns_iteration_args *a, void *stream)
+{
+    return a ? launch_columns_iteration<double>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
+ISLS_API int isls_columns_iteration_f32(const isls_columns_iteration_args *a, void *stream)
+{
+    return a ? launch_columns_iteration<float>(*a, (hipStream_t)stream) : ISLS_ERR_ARG;
+}
 ISLS_API int isls_accept_step_f64(const isls_accept_args *a, void *stream)
 {
     if (a && a->B == 0) return ISLS_OK;

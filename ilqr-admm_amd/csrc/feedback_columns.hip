@@ -426,4 +426,72 @@ int launch_columns_admm(const isls_columns_admm_args &a, hipStream_t s)
 template int launch_columns_admm<double>(const isls_columns_admm_args &, hipStream_t);
 template int launch_columns_admm<float>(const isls_columns_admm_args &, hipStream_t);
 
+// ------------------------------------------------------------------------------------------------
+// Behind the line search on column 0 (isls/isls.py:593-606): du[0] <- alpha* du[0], dx[0] <- x_noms[ind] - x_nom for the active
+// problems (flat sweep, one wavefront per problem).
+template <typename T>
+__global__ __launch_bounds__(64) void columns_step_kernel(int N, int n, int m, const T *alphas, const int32_t *best, const T *x_out,
+                                                          const T *xhat, T *dx0, T *du0, const int32_t *active)
+{
+    const int b = blockIdx.x;
+    if (active && active[b] == 0) return;
+    const T step = alphas[best[b]];
+    const int64_t ox = (int64_t)b * N * n, ou = (int64_t)b * N * m;
+    for (int e = threadIdx.x; e < N * m; e += kWave) du0[ou + e] *= step;
+    for (int e = threadIdx.x; e < N * n; e += kWave) dx0[ox + e] = x_out[ox + e] - xhat[ox + e];
+}
+
+template <typename T>
+int launch_columns_iteration(const isls_columns_iteration_args &a, hipStream_t s)
+{
+    const isls_columns_args &c = a.cols;
+    const int C = c.C, B = c.B, N = c.N, n = c.n, m = c.m;
+    if (B < 0 || C < 1) return ISLS_ERR_ARG;
+    if (B == 0) return ISLS_OK;
+    int rc;
+    // ---- x-step: C feed-forward passes, then the column rollout ---------------------------------------------------------
+    isls_ff_args f = a.ff;
+    f._pad = C;
+    rc = (C > 1 && a.ff._pad != 1) ? launch_ff<T>(f, s) : ISLS_ERR_UNSUPPORTED;   // ff._pad == 1: one pass per column asked for
+    if (rc == ISLS_ERR_UNSUPPORTED) {                          // one pass per column
+        if (C > 1 && (!a.zero_x || !a.zero_u)) return ISLS_ERR_ARG;
+        for (int col = 0; col < C; ++col) {
+            isls_ff_args g = a.ff;
+            g._pad = 0;
+            const int64_t ox = (int64_t)col * B * N * n * (int64_t)sizeof(T), ou = (int64_t)col * B * N * m * (int64_t)sizeof(T);
+            auto off = [](const void *p, int64_t o) -> const void * { return p ? (const char *)p + o : nullptr; };
+            g.zx = off(a.ff.zx, ox); g.lx = off(a.ff.lx, ox); g.zu = off(a.ff.zu, ou); g.lu = off(a.ff.lu, ou);
+            g.k = (char *)a.ff.k + ou;
+            if (col > 0) { g.c0x = isls_view{a.zero_x, 0, 0}; g.c0u = isls_view{a.zero_u, 0, 0}; }
+            if ((rc = launch_ff<T>(g, s)) != ISLS_OK) return rc;
+        }
+    } else if (rc != ISLS_OK) {
+        return rc;
+    }
+    if ((rc = launch_columns_rollout<T>(c, s)) != ISLS_OK) return rc;
+    // ---- line search on column 0 and its step ---------------------------------------------------------------------------
+    if (a.ls.L > 0) {
+        if (!a.ls.best || !a.ls.alphas || !a.ls.x_out || !a.ls.xhat) return ISLS_ERR_ARG;
+        if ((rc = launch_rollout<T>(a.ls, s)) != ISLS_OK) return rc;
+        hipLaunchKernelGGL((columns_step_kernel<T>), dim3(B), dim3(64), 0, s, N, n, m, (const T *)a.ls.alphas, (const int32_t *)a.ls.best,
+                           (const T *)a.ls.x_out, (const T *)a.ls.xhat, (T *)c.dx, (T *)c.du, a.ls.active);
+        if ((rc = check_launch()) != ISLS_OK) return rc;
+    }
+    // ---- z-step ---------------------------------------------------------------------------------------------------------
+    if (a.admm.xx || a.admm.xu) {
+        isls_columns_admm_args z = a.admm;
+        z.phase = 0;
+        if ((rc = launch_columns_admm<T>(z, s)) != ISLS_OK) return rc;
+        if (a.admm.xx && a.proj_x && (rc = launch_project<T>(*a.proj_x, s)) != ISLS_OK) return rc;
+        if (a.admm.xu && a.proj_u && (rc = launch_project<T>(*a.proj_u, s)) != ISLS_OK) return rc;
+        z.phase = 1;
+        if ((rc = launch_columns_admm<T>(z, s)) != ISLS_OK) return rc;
+        if (a.log && hipMemcpyAsync(a.log, a.admm.res, sizeof(T) * (size_t)B * 2, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return ISLS_ERR_LAUNCH;
+    }
+    return ISLS_OK;
+}
+template int launch_columns_iteration<double>(const isls_columns_iteration_args &, hipStream_t);
+template int launch_columns_iteration<float>(const isls_columns_iteration_args &, hipStream_t);
+
 }  // namespace isls

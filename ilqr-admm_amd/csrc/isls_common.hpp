@@ -213,6 +213,7 @@ int launch_sls_closed_loop(int M, int N, int n, int m, const void *A, const void
 template <typename T> int launch_dense_closed_loop(const isls_dense_loop_args &a, hipStream_t s);
 template <typename T> int launch_columns_rollout(const isls_columns_args &a, hipStream_t s);
 template <typename T> int launch_columns_admm(const isls_columns_admm_args &a, hipStream_t s);
+template <typename T> int launch_columns_iteration(const isls_columns_iteration_args &a, hipStream_t s);
 template <typename T> int launch_expand(const isls_expand_args &a, hipStream_t s);
 template <typename T> int launch_linearize(const isls_linearize_args &a, hipStream_t s);
 template <typename T> int launch_accept(const isls_accept_args &a, hipStream_t s);

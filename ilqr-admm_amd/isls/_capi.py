@@ -172,6 +172,11 @@ class OuterArgs(C.Structure):
                 ("log", C.c_void_p), ("outer_active", C.c_void_p), ("timing", C.c_void_p)]
 
 
+class ColumnsIterationArgs(C.Structure):
+    _fields_ = [("ff", FfArgs), ("cols", ColumnsArgs), ("ls", RolloutArgs), ("admm", ColumnsAdmmArgs),
+                ("proj_x", C.c_void_p), ("proj_u", C.c_void_p), ("zero_x", C.c_void_p), ("zero_u", C.c_void_p), ("log", C.c_void_p)]
+
+
 class AdvanceArgs(C.Structure):
     _fields_ = [("accept", AcceptArgs), ("lin", LinearizeArgs), ("exp", ExpandArgs),
                 ("admm_active", C.c_void_p), ("iters", C.c_void_p), ("lx", C.c_void_p), ("lu", C.c_void_p), ("res_prev", C.c_void_p)]
@@ -180,7 +185,7 @@ class AdvanceArgs(C.Structure):
 # names every build of the library must export (checked by tests/test_capi_symbols.py)
 EXPORTED = [f"isls_{k}_{s}" for s in ("f64", "f32") for k in
             ("riccati_gain", "riccati_ff", "riccati_gain_ff", "riccati_ff_prepare", "rollout_ls", "admm_update", "project_rows", "sls_admm", "sls_closed_loop", "columns_rollout", "columns_admm", "dense_closed_loop", "expand_quadratic", "linearize",
-             "accept_step", "reduce_convergence", "reduce_convergence_table", "ilqr_admm_outer", "outer_advance")] + \
+             "accept_step", "reduce_convergence", "reduce_convergence_table", "ilqr_admm_outer", "outer_advance", "columns_iteration")] + \
            ["isls_ff_segments", "isls_ff_record_elems", "isls_version", "isls_dims_supported", "isls_dims_generic", "isls_error_string", "isls_timing_create",
             "isls_timing_destroy", "isls_timing_reset", "isls_timing_pause", "isls_timing_read_ms"]
 
@@ -613,7 +618,11 @@ class Kernels:
         a.x0, a.x_log, a.u_log = _ptr(_dense(x0, (M, n), "x0")), _ptr(x_log), _ptr(_dense(u_log, (M, N, m), "u_log"))
         return self._call("dense_closed_loop", _sfx(x_log), a, stream)
 
-    def columns_rollout(self, A, Bm, Cuu, c0u, K, k, dx, du, Rr=None, zu=None, lu=None, active=None, stream=None):
+    def columns_rollout(self, *args, stream=None, **kw):
+        return self._call("columns_rollout", _sfx(args[6]), self.columns_args(*args, **kw), stream)
+
+    @staticmethod
+    def columns_args(A, Bm, Cuu, c0u, K, k, dx, du, Rr=None, zu=None, lu=None, active=None):
         """isls_columns_rollout: k, dx, du column-major [C,B,N,.]; A, Bm, Cuu, c0u, Rr broadcastable views."""
         Cc, B, N, n = dx.shape
         m = du.shape[3]
@@ -625,10 +634,14 @@ class Kernels:
         a.zu, a.lu = _ptr(_dense(zu, (Cc, B, N, m), "zu")), _ptr(_dense(lu, (Cc, B, N, m), "lu"))
         a.dx, a.du = _ptr(_dense(dx, (Cc, B, N, n), "dx")), _ptr(_dense(du, (Cc, B, N, m), "du"))
         a.active = _ptr(active)
-        return self._call("columns_rollout", _sfx(dx), a, stream)
+        return a
 
-    def columns_admm(self, phase, dims, res, res_prev, x=None, u=None, relax=1.0, tol_abs=0.0, tol_rel=1e-3, active=None,
-                     iters=None, stream=None):
+    def columns_admm(self, phase, dims, res, res_prev, x=None, u=None, stream=None, **kw):
+        a = self.columns_admm_args(phase, dims, res, res_prev, x=x, u=u, **kw)
+        return self._call("columns_admm", _sfx((x or u)["xx"]), a, stream)
+
+    @staticmethod
+    def columns_admm_args(phase, dims, res, res_prev, x=None, u=None, relax=1.0, tol_abs=0.0, tol_rel=1e-3, active=None, iters=None):
         """isls_columns_admm; dims = (B, N, n, m, C); x / u: dict(xx, z, l, z_prev, work, W, nom=None) or None."""
         B, N, n, m, Cc = dims
         a = ColumnsAdmmArgs(B=B, N=N, n=n, m=m, C=Cc, phase=int(phase), relax=float(relax), tol_abs=float(tol_abs),
@@ -644,8 +657,25 @@ class Kernels:
             setattr(a, names[6], make_view(blk["W"], B, N, (d, d), names[6]))
         a.res, a.res_prev = _ptr(_dense(res, (B, 2), "res")), _ptr(_dense(res_prev, (B, 2), "res_prev"))
         a.active, a.iters = _ptr(active), _ptr(iters)
-        sample = (x or u)["xx"]
-        return self._call("columns_admm", _sfx(sample), a, stream)
+        return a
+
+    @staticmethod
+    def columns_iteration_args(ff, cols, ls, admm, proj_x=None, proj_u=None, zero_x=None, zero_u=None, log=None):
+        """isls_columns_iteration_args from the blocks of ff_args / columns_args / rollout_args (None: no line search) /
+        columns_admm_args (None: unconstrained) and the row-projection descriptors of the two blocks."""
+        a = ColumnsIterationArgs(ff=ff, cols=cols)
+        if ls is not None:
+            a.ls = ls
+        if admm is not None:
+            a.admm = admm
+        a.proj_x = C.addressof(proj_x) if proj_x is not None else None
+        a.proj_u = C.addressof(proj_u) if proj_u is not None else None
+        a.zero_x, a.zero_u, a.log = _ptr(zero_x), _ptr(zero_u), _ptr(log)
+        a._keep = (ff, cols, ls, admm, proj_x, proj_u)
+        return a
+
+    def columns_iteration(self, it, sfx, stream=None):
+        return self._call("columns_iteration", sfx, it, stream)
 
     def sls_closed_loop(self, A, Bm, K, k, x0, x_log, u_log, stream=None):
         M, N, n = x_log.shape

@@ -135,6 +135,43 @@ class ColumnSolver:
                                    Rr=e.Rr if bu is not None else None, zu=bu["z"] if bu is not None else None,
                                    lu=bu["l"] if bu is not None else None, active=act, stream=_stream_ptr())
 
+    def iteration_args(self, L, zero_K, relax, tol_abs, tol_rel):
+        """isls_columns_iteration_args of one ADMM iteration on this solver's buffers (call after prepare()): feed-forward passes
+        of the C columns, column rollout, open-loop line search over alphas[:L] on column 0 (L = 0: none), z-step."""
+        e, bx, bu, K = self.e, self.blocks["x"], self.blocks["u"], capi.Kernels
+        C_ = self.C
+        zc = lambda d: torch.zeros(C_, e.B, e.N, d, dtype=e.dtype, device=e.device)      # noqa: E731
+        if not hasattr(self, "_zero_cx"):
+            self._zero_cx, self._zero_cu = (zc(e.n) if bx is None else None), (zc(e.m) if bu is None else None)
+        zx, lx = (bx["z"], bx["l"]) if bx is not None else (self._zero_cx, self._zero_cx)
+        zu, lu = (bu["z"], bu["l"]) if bu is not None else (self._zero_cu, self._zero_cu)
+        ff = K.ff_args(e.A, e.Bm, e.c0x, e.c0u, e.K, e.Quu, e.fac, e.Qux, self.kcol, Qr=e.Qr, Rr=e.Rr,
+                       zx=zx if e.Qr is not None else None, lx=lx if e.Qr is not None else None,
+                       zu=zu if e.Rr is not None else None, lu=lu if e.Rr is not None else None, solve_mode=e.solve_mode,
+                       active=e.admm_active, seg=self.seg_cols, rec=self.rec, ncol=C_)
+        if self.rec is None:                                    # array form: the factors of the gain pass
+            ff.Quu, ff.fac, ff.Qux = e.Quu.data_ptr(), e.fac.data_ptr(), e.Qux.data_ptr()
+        if not self._columns_in_one_launch():
+            ff._pad = 1                                         # one feed-forward launch per column
+        cols = K.columns_args(e.A, e.Bm, self.Cuu, e.c0u, e.K, self.kcol, self.dx, self.du, Rr=e.Rr if bu is not None else None,
+                              zu=bu["z"] if bu is not None else None, lu=bu["l"] if bu is not None else None, active=e.admm_active)
+        ls = None
+        if L > 0:
+            ls = K.rollout_args(e.model, e.model_par, zero_K, self.du[0], e.xhat, e.uhat, e.alphas[:L], e.Qtab, e.ztab, e.seq, e.u_std,
+                                e.xx, e.xu, best=e.best, cost_new=e.cost_new, flags=0, status=e.status, active=e.admm_active,
+                                q_nonzero=e.q_nonzero, cost_model=e.cost_model, cost_par=e.cost_par)
+        admm = None
+        if self.constrained:
+            noms = {"x": e.xhat, "u": e.uhat}
+            for key, blk in self.blocks.items():
+                if blk is not None:
+                    blk["nom"] = noms[key] if (self.nominal_in_projection and blk["desc"] is not None) else None
+            admm = K.columns_admm_args(0, (e.B, e.N, e.n, e.m, C_), e.res, e.res_prev, x=bx, u=bu, relax=relax, tol_abs=tol_abs,
+                                       tol_rel=tol_rel, active=e.admm_active, iters=e.admm_iters)
+        self._keep_alphas = e.alphas[:L]
+        return K.columns_iteration_args(ff, cols, ls, admm, proj_x=bx["desc"] if bx is not None else None,
+                                        proj_u=bu["desc"] if bu is not None else None, zero_x=self.zero_x, zero_u=self.zero_u)
+
     def z_step(self, relax, tol_abs, tol_rel, log_row=None):
         """z = Proj(relax x + (1 - relax) z + lmb), lmb += x - z, rho-scaled residuals and the two stop rules"""
         e, bx, bu = self.e, self.blocks["x"], self.blocks["u"]
@@ -251,8 +288,11 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     e.hist_len.fill_(1)
     mask3 = lambda a: a.to(torch.bool).view(B, 1, 1)                          # noqa: E731
     device_only = not self._host_ls and all(blk is None or blk["desc"] is not None for blk in cs.blocks.values())
-    graph = dict(g=None, eager_done=False, ptrs=None) if (device_only and cs.constrained and e.profile_events is None and
-                                                          os.environ.get("ISLS_ADMM_GRAPH", "1") != "0") else None
+    # everything on the device: ONE C call per ADMM iteration (isls_columns_iteration_*: feed-forward passes, column rollout,
+    # line search and its step, z-step around the row projections -- ~12 launches on fixed buffers).  Round 2 replayed a HIP
+    # graph of the iteration instead; recording it cost 55-80 ms per isls_admm call, more than ten outer iterations take.
+    use_driver = device_only and e.profile_events is None and os.environ.get("ISLS_ADMM_DRIVER", "1") != "0"
+    drv = dict(args=None, ptrs=None)
     host_sync = self._host_ls or self._host_cost or not device_only or verbose   # host callbacks need the numbers anyway
     outer_count = torch.zeros(B, dtype=torch.int32, device=e.device)
     outer_lag = _LaggedAny(e.device, int(k_max))
@@ -275,10 +315,6 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
         self._linearize(get_AB)
         self._expand_regularised(get_Cs)                                        # built-in cost on the device, else the caller's get_Cs (isls.py:548-560)
         cs.prepare(e.outer_active)
-        if graph is not None and graph["g"] is not None and graph["ptrs"] != captured_pointers():
-            # a buffer of the recorded iteration was re-allocated (e.g. a get_AB callback whose arrays changed shape): the
-            # graph holds the old addresses -- drop it, run eagerly once, record again
-            graph.update(g=None, eager_done=False)
         cs.restart(e.outer_active)                                              # lmb restarts, z is warm-started (isls.py:613-616)
         inner_lag.reset()
         act = e.admm_active
@@ -302,36 +338,19 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
             if cs.constrained:
                 cs.z_step(alpha, threshold, 1e-3)                               # isls.py:626-665
 
+        if use_driver and (drv["args"] is None or drv["ptrs"] != captured_pointers()):
+            drv.update(args=cs.iteration_args(L, zero_K, alpha, threshold, 1e-3), ptrs=captured_pointers())
         for j in range(J):
-            if graph is not None and graph["g"] is not None:
-                graph["g"].replay()
-            elif graph is not None and graph["eager_done"]:
-                # second iteration of the call: record the launches of one ADMM iteration (same buffers every iteration) in a
-                # HIP graph and replay it from now on -- the Python / ctypes work per launch (~25 launches, ~1 ms) was what
-                # bounded this loop, not its 0.65 ms of kernels
-                g = torch.cuda.CUDAGraph()
-                try:
-                    with torch.cuda.graph(g):
-                        admm_iteration()
-                except RuntimeError as exc:                                     # capture refused by the runtime: stay on the eager path
-                    # (IslsError / ValueError of a launch are bugs, not refusals: they propagate)
-                    if isinstance(exc, capi.IslsError):
-                        raise
-                    import warnings
-                    warnings.warn(f"isls_admm: HIP graph capture of the ADMM iteration failed ({exc}); running eagerly", RuntimeWarning)
-                    graph = None
-                    admm_iteration()
-                else:
-                    graph.update(g=g, ptrs=captured_pointers())
-                    g.replay()
+            if use_driver:
+                drv["args"].log = logbuf[j].data_ptr() if cs.constrained else None
+                e.kern.columns_iteration(drv["args"], e.sfx, stream=_stream_ptr())
             else:
                 admm_iteration()
-                if graph is not None:
-                    graph["eager_done"] = True
             if not cs.constrained:
                 e.admm_iters.add_(act)
                 break
-            logbuf[j].copy_(e.res)
+            if not use_driver:
+                logbuf[j].copy_(e.res)
             inner_lag.push(act)
             if inner_lag.seen_all_inactive():
                 break

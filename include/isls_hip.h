@@ -483,6 +483,34 @@ int isls_columns_admm_f64(const isls_columns_admm_args *a, void *stream);
 int isls_columns_admm_f32(const isls_columns_admm_args *a, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * One ADMM iteration of isls_admm (isls/isls.py:578-665) enqueued as a whole -- the feedback-column counterpart of
+ * isls_ilqr_admm_outer_*:
+ *   x-step   : the C feed-forward passes (`ff` in the column layout of ff._pad = C: one launch on the packed records where that
+ *              form applies, else -- or when ff._pad == 1 asks for it -- one pass per column:
+ *              the driver then offsets zx, lx, zu, lu, k per column and hands columns >= 1 the zero vectors zero_x / zero_u as
+ *              cost gradients), then isls_columns_rollout (`cols`);
+ *   line search on column 0 (`ls`, skipped when ls.L == 0: SLS.ADMM_SLS has none): isls_rollout_ls of u_nom + alpha d_u with
+ *              zero gains (ls.K a zero array, ls.k = du[0]), then  du[0] <- alpha* du[0],  dx[0] <- x_out - xhat  for the active
+ *              problems (isls.py:593-606);
+ *   z-step   : isls_columns_admm phase 0, the row projections (proj_x / proj_u, nullable: block absent), phase 1 (`admm`;
+ *              skipped when both blocks are absent: the unconstrained problem has no z-step);
+ *   `log`    : nullable [B,2], receives admm.res behind the z-step.
+ * Nothing is exchanged with the host between the launches.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct isls_columns_iteration_args {
+    isls_ff_args ff;
+    isls_columns_args cols;
+    isls_rollout_args ls;
+    isls_columns_admm_args admm;
+    const isls_project_args *proj_x, *proj_u;
+    const void *zero_x, *zero_u;    /* [n], [m] zeros (cost gradients of the columns >= 1 in the one-pass-per-column form) */
+    void *log;
+} isls_columns_iteration_args;
+
+int isls_columns_iteration_f64(const isls_columns_iteration_args *a, void *stream);
+int isls_columns_iteration_f32(const isls_columns_iteration_args *a, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Quadratic via-point cost expansion about the nominal (the `Cts is None` branch of
  * backward_pass_DP, isls/isls.py:263-271, written out as arrays, plus the ADMM regulariser):
  *   Cxx[b,t] = 2 Q_t (+ 2 Qr_t) ; Cuu[b,t] = 2 u_std I (+ 2 Rr_t)

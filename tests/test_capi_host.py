@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     import subprocess
     import tempfile
     names = ["gain", "ff", "ff_prepare", "rollout", "admm", "project", "sls_admm", "expand", "linearize", "accept", "outer",
-             "columns", "columns_admm", "dense_loop", "advance"]
+             "columns", "columns_admm", "dense_loop", "advance", "columns_iteration"]
     src = '#include <stdio.h>\n#include "isls_hip.h"\nint main(){' + "".join(
         f'printf("%zu\\n", sizeof(isls_{n}_args));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
@@ -44,7 +44,7 @@ def test_struct_layouts_match_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "s"), os.path.join(d, "s.c")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     structs = [capi.GainArgs, capi.FfArgs, capi.FfPrepareArgs, capi.RolloutArgs, capi.AdmmArgs, capi.ProjectArgs, capi.SlsAdmmArgs, capi.ExpandArgs, capi.LinearizeArgs,
-               capi.AcceptArgs, capi.OuterArgs, capi.ColumnsArgs, capi.ColumnsAdmmArgs, capi.DenseLoopArgs, capi.AdvanceArgs]
+               capi.AcceptArgs, capi.OuterArgs, capi.ColumnsArgs, capi.ColumnsAdmmArgs, capi.DenseLoopArgs, capi.AdvanceArgs, capi.ColumnsIterationArgs]
     assert sizes == [ctypes.sizeof(s) for s in structs]
 
 

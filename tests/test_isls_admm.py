@@ -287,13 +287,17 @@ def test_feedback_columns_in_one_launch_equal_one_launch_per_column(golden, monk
     kw = dict(max_line_search=30, k_max=2, project_u=cs, rho_u=1.0, max_admm_iter=4, threshold=0.0)
     monkeypatch.setenv("ISLS_FF_NSEG", nseg)
     out = {}
-    for mode in ("1", "0"):
+    # ... and the C driver of the ADMM iteration (isls_columns_iteration_*: one call per iteration) against the same launches
+    # made one by one from the host
+    for mode, drv in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("ISLS_ADMM_FF_COLUMNS", mode)
+        monkeypatch.setenv("ISLS_ADMM_DRIVER", drv)
         s = make_arm(cfg, [0, 1])
         du, phi = s.isls_admm(3, None, **kw)
-        out[mode] = (du, phi, np.array(s.x_nom), np.array(s.u_nom), np.array(s.cost_log), s.admm_logs)
-    for a, b in zip(out["1"], out["0"]):
-        assert np.array_equal(a, b)
+        out[mode + drv] = (du, phi, np.array(s.x_nom), np.array(s.u_nom), np.array(s.cost_log), s.admm_logs)
+    for key in ("01", "10", "00"):
+        for a, b in zip(out["11"], out[key]):
+            assert np.array_equal(a, b), key
 
 
 @pytest.mark.gpu
