@@ -44,6 +44,7 @@ struct RoP {
     int B, N, L, flags, nseg, seg_len;
     int seg_lanes;                 // lanes per replay segment: 1, or NU (one control row per lane)
     int stage_on;                  // winner trajectory collected in LDS and written out in one sweep (it fits the slot)
+    int tpw;                       // trajectories (slots) per wavefront: 64 / max(L, 8), or fewer when that keeps the stage on chip
     int u_off;                     // element offset of the winner's u rows [N][NU] in the slot's region (behind x [N][NX] and, with
                                    // the recording on, behind the search's records and checkpoints: they are written DURING the search)
     const T *par;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
     T *lds = reinterpret_cast<T *>(ro_smem);
 
     const int L = p.L, N = p.N, NSEG = p.nseg, S = p.seg_len;
-    const int GL = L > 8 ? L : 8, TPW = kWave / GL;
+    const int GL = L > 8 ? L : 8, TPW = p.tpw;
     const bool stage_on = p.stage_on != 0;
     constexpr int MDLW = Model<T, NX, NU, MODEL>::LDS_WORDS;
     const int SLOT = LY::slot_elems(L, GL, NSEG, N, stage_on, MDLW);
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
         pred = pred < 0 ? 0 : (pred < L ? pred : L - 1);
     }
     const bool is_pred = stage_on && c == pred;
-    T *const udump = c_aug + c;                                // c < 2 GL: extra idle lanes are fewer than a slot's lanes
+    T *const udump = c_aug + (c < 2 * GL ? c : c % (2 * GL));  // the slot's 2 GL cost words (extra idle lanes of a narrow wavefront share)
     T *urw = is_pred ? ustage : udump;                         // running: u_t of the step the search is at
     const int ust = is_pred ? 1 : 0, uadv = is_pred ? NU : 0;
     // ================================ SEARCH ==========================================================
@@ -997,21 +998,46 @@ template <typename T, int NX, int NU, int MODEL>
 int launch_rollout_family_impl(RoP<T> &p, const isls_rollout_args &a, hipStream_t s, bool want_fused, bool *stage_ok)
 {
     using LY = RoLayout<NX, NU>;
-    const int GL = a.L > 8 ? a.L : 8, TPW = kWave / GL;
-    const int grid = (a.B + TPW - 1) / TPW;
+    const int GL = a.L > 8 ? a.L : 8;
+    int TPW = kWave / GL;
+    // two waves per SIMD where a batch of 4096 launches more waves than SIMDs (slots of >= 16 lanes), the whole register
+    // file for the 8-lane slots (8 trajectories per wave) and the 9-state models in 16-lane slots (4 per wave)
+    const bool occ2 = GL >= 32 || (GL >= 16 && NX < 9);
     // winner replay geometry: NSEG segments of S steps; a segment is replayed by one lane or by NU lanes (one control row
     // each, ro_replay).  An iteration of the one-lane form is a scattered gather (~4x the time of the row form's), so the
     // row form wins unless it gets far fewer segments
     bool stage_on = true;
     constexpr int MDLW = Model<T, NX, NU, MODEL>::LDS_WORDS;
     auto smem_bytes = [&](int ns) { return (size_t)TPW * LY::slot_elems(a.L, GL, ns, a.N, stage_on, MDLW) * sizeof(T); };
-    // the winner's trajectory is collected in LDS when that keeps the workgroup under 28 KB (>= 5 per CU); longer horizons
-    // store it step by step
-    if (smem_bytes(1) > 28 * 1024) stage_on = false;
+    // the winner's trajectory is collected in LDS when that keeps the workgroup under 28 KB (>= 5 per CU) ...
+    size_t lds_limit = 26 * 1024 + 512;                        // <= 26.5 KB per wavefront keeps 6 workgroups per CU
+    if (smem_bytes(1) > 28 * 1024) {
+        // ... longer horizons (the car's N = 200) get FEWER trajectories per wavefront instead, as long as every wavefront of
+        // the launch is still resident (two per SIMD at most, the CU's 160 KB shared by its wavefronts): the stage is what
+        // lets a recorded winner skip the replay.  Beyond that the trajectory is stored step by step.
+        // (only where the element-wise ADMM update can then ride on the launch -- config 3: 10 x (181 + 47) -> 10 x 218 us;
+        // without that the extra wavefronts cost more than the replay they save: config 4, 199 vs 190 us per launch)
+        stage_on = false;
+        const int full = TPW;
+        for (int t2 = want_fused ? full - 1 : 0; t2 >= 1; --t2) {
+            const int waves = (a.B + t2 - 1) / t2, per_cu = (waves + 255) / 256;
+            if (waves > (occ2 ? 2048 : 1024)) break;
+            const size_t lim = (size_t)(160 * 1024) / per_cu - 256;
+            const size_t need = (size_t)t2 * LY::slot_elems(a.L, GL, 1, a.N, true, MDLW) * sizeof(T);
+            if (need <= lim && need <= 60 * 1024) {
+                TPW = t2;
+                stage_on = true;
+                lds_limit = lim < 60 * 1024 ? lim : 60 * 1024;
+                break;
+            }
+        }
+    }
+    const int grid = (a.B + TPW - 1) / TPW;
+    p.tpw = TPW;
     auto fit = [&](int ns) {
         if (ns > a.N) ns = a.N;
         if (ns > kMaxSeg) ns = kMaxSeg;
-        while (ns > 1 && smem_bytes(ns) > 26 * 1024 + 512) --ns;   // <= 26.5 KB per wavefront keeps 6 workgroups per CU
+        while (ns > 1 && smem_bytes(ns) > lds_limit) --ns;
         return ns < 1 ? 1 : ns;
     };
     const int ns1 = fit(GL), nsr = NU > 1 ? fit(GL / NU) : 0;
@@ -1025,16 +1051,12 @@ int launch_rollout_family_impl(RoP<T> &p, const isls_rollout_args &a, hipStream_
     p.u_off = LY::u_off(a.L, p.nseg, a.N);
     if (stage_ok) *stage_ok = stage_on;
     if (!stage_on) p.fa_on = 0;                                 // the fused update reads x, u from the stage: the caller runs it as its own launch
-    (void)want_fused;
     const size_t smem = smem_bytes(p.nseg);
     if (smem > 64 * 1024) return ISLS_ERR_UNSUPPORTED;
     const bool absolute = (a.flags & ISLS_RO_ABSOLUTE) != 0;
     const int pairs = LY::pairs_needed(!absolute && a.xhat, !absolute && a.uhat, a.wq.p != nullptr, a.wq.p && a.wq.st != 0,
                                        a.wr.p != nullptr, a.wr.p && a.wr.st != 0);
     const int jm = (pairs + GL - 1) / GL;
-    // two waves per SIMD where a batch of 4096 launches more waves than SIMDs (slots of >= 16 lanes), the whole register
-    // file for the 8-lane slots (8 trajectories per wave) and the 9-state models in 16-lane slots (4 per wave)
-    const bool occ2 = GL >= 32 || (GL >= 16 && NX < 9);
     // instantiated load-slot counts: 1, 2, 3 and the family's maximum for its narrowest slots of that occupancy class
     constexpr int J2MAX = (LY::MAXPAIRS + 15) / 16, J1MAX = (LY::MAXPAIRS + 7) / 8;
     if (occ2) {

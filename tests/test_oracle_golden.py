@@ -425,10 +425,11 @@ def _run_sls_admm(kern, c, g, dtype=np.float64, wrap=lambda a: a, sel=None, max_
 
 
 def fp32_tols(g):
-    """Per-problem fp32 tolerance of du / phi_u: the north star's 1e-4, or ten times the movement of the REFERENCE's own
+    """Per-problem fp32 tolerance of du / phi_u: the north star's 1e-4, or three times the movement of the REFERENCE's own
     du, phi_u under fp32-rounding-sized perturbations of its inverses, target and constraint rows (golden key fp32_sens,
-    tests/golden/make_golden.py::gen_sls) where the problem's conditioning makes that larger."""
-    return [max(1e-4, 10.0 * float(np.max(s))) for s in g["fp32_sens"]]
+    tests/golden/make_golden.py::gen_sls) where the problem's conditioning makes that larger (round 2 allowed ten times: with
+    the committed fixtures that was up to 7.3e-4; three times is 2.2e-4 at most, DESIGN 2 lists the values)."""
+    return [max(1e-4, 3.0 * float(np.max(s))) for s in g["fp32_sens"]]
 
 
 def _check_sls_admm(run, c, g, tol, only_converged=False, x_tols=None):
