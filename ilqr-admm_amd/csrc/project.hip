@@ -43,9 +43,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 2 : 1)) void project_rows_ke
         sets[s].b = p.b[s] ? p.b[s] + (int64_t)pb * p.b_sp[s] : nullptr;
         sets[s].par = p.par[s] ? p.par[s] + (int64_t)pb * p.par_sp[s] : nullptr;
     }
-#ifdef ISLS_SET_STAGE                                              // experiment, off: measured slower (see stage_sets in projections.hpp)
+#ifdef ISLS_PROJECT_SET_STAGE                                      // opt-in here: measured 7 % slower for config 4's rows (151 vs 141 us:
+                                                                   // the fp64 kernel spills more); sls_admm.hip has it on (+13-19 %)
     __shared__ T set_lds[kMaxSets * kSetLdsWords];
-    stage_sets<T>(sets, p.nsets, D, set_lds);
+    CSetLds<T> lsets[kMaxSets];
+    stage_sets_lds<T>(sets, lsets, p.nsets, D, set_lds);
+#else
+    CSet<T> (&lsets)[kMaxSets] = sets;
 #endif
     int it = 0;
     if (p.algorithm == ISLS_PROJ_ALG_ADMM && p.nsets == 1 && sets[0].A == nullptr) {   // direct primitive
@@ -80,11 +84,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 2 : 1)) void project_rows_ke
             b = mb;
         };
         if (p.algorithm == ISLS_PROJ_ALG_DYKSTRA)
-            it = dykstra_row<T, D>(x0, p.nsets, sets, p.max_iter, p.threshold, x, block_max);
+            it = dykstra_row<T, D>(x0, p.nsets, lsets, p.max_iter, p.threshold, x, block_max);
         else if (p.algorithm == ISLS_PROJ_ALG_SOC)
-            it = project_soc_row<T, D>(x0, sets[0], p.rho, p.max_iter, p.threshold, x, block_max);
+            it = project_soc_row<T, D>(x0, lsets[0], p.rho, p.max_iter, p.threshold, x, block_max);
         else
-            it = project_set_convex_row<T, D>(x0, p.nsets, sets, p.rho, p.max_iter, p.threshold, x, block_max);
+            it = project_set_convex_row<T, D>(x0, p.nsets, lsets, p.rho, p.max_iter, p.threshold, x, block_max);
     }
     if (inr) {
         T *dst = p.y_out + (int64_t)pb * p.out_sp + (int64_t)r * p.out_sr;

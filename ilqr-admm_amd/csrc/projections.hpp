@@ -19,15 +19,18 @@ constexpr int kMaxRowDim = ISLS_MAX_ROW_DIM;   // d
 constexpr int kMaxSetDim = ISLS_MAX_SET_DIM;   // dim_i of A_i y + b_i
 constexpr int kMaxSets = ISLS_MAX_SETS;
 
-template <typename T>
+// P: pointer type of the operands -- `const T *` (global memory) or the LDS form below (stage_sets_lds)
+template <typename T, typename P = const T *>
 struct CSet {
     int kind, dim;
-    const T *A, *b, *par;          // this problem's A [dim,d], b [dim], parameters
+    P A, b, par;                   // this problem's A [dim,d], b [dim], parameters
 };
+template <typename T> using LdsPtr = const __attribute__((address_space(3))) T *;
+template <typename T> using CSetLds = CSet<T, LdsPtr<T>>;
 
 // Words of a set's parameter block (include/isls_hip.h ISLS_SET_*): what stage_sets copies
-template <typename T>
-__device__ __forceinline__ int set_par_words(int kind, int dim, const T *par)
+template <typename P>
+__device__ __forceinline__ int set_par_words(int kind, int dim, P par)
 {
     switch (kind) {
         case ISLS_SET_BOX: return 2 * dim;
@@ -42,15 +45,16 @@ __device__ __forceinline__ int set_par_words(int kind, int dim, const T *par)
 constexpr int kSetParMax = 3 + kMaxSetDim + 2 * kMaxSetDim * kMaxSetDim;                 // the keep-out square with q = dim
 constexpr int kSetLdsWords = kMaxSetDim * kMaxRowDim + kMaxSetDim + kSetParMax;           // A | b | par of one set
 
-// EXPERIMENT (-DISLS_SET_STAGE), measured and NOT adopted.  The sets of a problem are the same for all of its rows, and the inner
-// iterations of project_set_convex read A_i, b_i and the primitive's parameters again and again from global memory (L2 hits;
-// rocprofv3: the wavefronts of config 5 are parked on waits for 60 % of their life).  Copying them into LDS and repointing the
-// descriptors there turns those reads into FLAT loads (the descriptors hold generic pointers), and those ran slower than the
-// L2 hits they replace: config 5 DI-1D fp32 7100 vs 7729 it/s, DI-3D 2751 vs 3246; config 4's row projection 197 vs 141 us,
-// isls_admm's 98 vs 62 us.  A form that would pay needs the descriptors typed as LDS (ds_read), i.e. the set loops templated
-// on the address space.  `lds` holds kMaxSets * kSetLdsWords words.
+// The sets of a problem are the same for all of its rows, and the inner iterations of project_set_convex read A_i, b_i and the
+// primitive's parameters again and again: from global memory those are L2 round trips on every row's dependent chain (rocprofv3:
+// the wavefronts of config 5 are parked on waits for 60 % of their life).  Every thread of the workgroup calls this once: the
+// operands are copied into LDS and described by LDS-typed pointers (CSetLds).  A first form that only repointed the generic
+// descriptors turned the reads into flat loads and ran SLOWER than the L2 hits (config 5 DI-1D fp32 7100 vs 7729 it/s, DI-3D
+// 2751 vs 3246; config 4's row projection 197 vs 141 us).  With typed pointers (ds_read): config 5 DI-1D fp32 9234 vs 7745
+// it/s, fp64 6717 vs 5660, DI-3D fp32 3740 vs 3260, fp64 1585 vs 1403 (same box, interleaved) -- on in sls_admm.hip; config 4's
+// row projection 151 vs 141 us -- off in project.hip.  `lds` holds kMaxSets * kSetLdsWords words.
 template <typename T>
-__device__ __forceinline__ void stage_sets(CSet<T> (&sets)[kMaxSets], int nsets, int D, T *lds)
+__device__ __forceinline__ void stage_sets_lds(const CSet<T> (&sets)[kMaxSets], CSetLds<T> (&out)[kMaxSets], int nsets, int D, T *lds)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
 #pragma unroll
@@ -70,12 +74,13 @@ __device__ __forceinline__ void stage_sets(CSet<T> (&sets)[kMaxSets], int nsets,
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < kMaxSets; ++s) {
-        if (s < nsets) {
-            const T *base = lds + s * kSetLdsWords;
-            if (sets[s].A) sets[s].A = base;
-            if (sets[s].b) sets[s].b = base + kMaxSetDim * kMaxRowDim;
-            if (sets[s].par) sets[s].par = base + kMaxSetDim * kMaxRowDim + kMaxSetDim;
-        }
+        // typed LDS pointers: the set loops are templates over the descriptor type, so these reads compile to ds_read
+        const LdsPtr<T> base = (LdsPtr<T>)(lds + s * kSetLdsWords);
+        out[s].kind = sets[s].kind;
+        out[s].dim = sets[s].dim;
+        out[s].A = base;
+        out[s].b = base + kMaxSetDim * kMaxRowDim;
+        out[s].par = base + kMaxSetDim * kMaxRowDim + kMaxSetDim;
     }
 }
 
@@ -106,8 +111,8 @@ __device__ __forceinline__ void invert_spd(T (&M)[D][D], T (&Inv)[D][D])
 }
 
 // v[0..dim) <- primitive projection of v (in place)
-template <typename T>
-__device__ __forceinline__ void project_primitive(int kind, int dim, const T *par, T (&v)[kMaxSetDim])
+template <typename T, typename P = const T *>
+__device__ __forceinline__ void project_primitive(int kind, int dim, P par, T (&v)[kMaxSetDim])
 {
     if (kind == ISLS_SET_BOX) {                                // par = lo[dim], hi[dim]
 #pragma unroll
@@ -142,7 +147,7 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
         }
     } else if (kind == ISLS_SET_LINEAR) {                      // par = l, u, a[dim]
         const T l = par[0], u = par[1];
-        const T *a = par + 2;
+        const auto a = par + 2;
         T atx = T(0), ata = T(0);
 #pragma unroll
         for (int i = 0; i < kMaxSetDim; ++i)
@@ -177,7 +182,7 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
             }
     } else if (kind == ISLS_SET_SHELL) {                       // par = l, u, c[dim]: project_quadratic_batch(y - c, l, u) + c
         const T l = par[0], u = par[1];
-        const T *c = par + 2;
+        const auto c = par + 2;
         T w[kMaxSetDim], ss = T(0);
 #pragma unroll
         for (int i = 0; i < kMaxSetDim; ++i) {
@@ -197,7 +202,7 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
             }
     } else if (kind == ISLS_SET_MULTILINEAR) {                 // par = q, l[q], u[q], M[q*dim]   (project_multilinear)
         const int q = (int)par[0];
-        const T *l = par + 1, *u = l + q, *Mm = u + q;
+        const auto l = par + 1; const auto u = l + q; const auto Mm = u + q;
         T Ax[kMaxSetDim], G[kMaxSetDim][kMaxSetDim], Gi[kMaxSetDim][kMaxSetDim], mu[kMaxSetDim];
 #pragma unroll
         for (int i = 0; i < kMaxSetDim; ++i) {
@@ -244,7 +249,7 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
     } else if (kind == ISLS_SET_SQUARE) {                      // par = q, l, u, c[q], W[q*q], Winv[q*q]
         const int q = (int)par[0];
         const T l = par[1], u = par[2];
-        const T *c = par + 3, *W = c + q, *Wi = W + q * q;
+        const auto c = par + 3; const auto W = c + q; const auto Wi = W + q * q;
         T y[kMaxSetDim], w[kMaxSetDim];
 #pragma unroll
         for (int i = 0; i < kMaxSetDim; ++i) y[i] = i < q ? v[i] - c[i] : T(0);
@@ -288,8 +293,8 @@ __device__ __forceinline__ void project_primitive(int kind, int dim, const T *pa
 // project_set_convex for ONE row x0[D] (isls/projections.py:289-374).  `block_max(a, b)` must return the maxima of
 // a and b over every row of the same call (the reference stops all rows of a call together: np.max over rows and
 // sets); rows that do not exist pass zeros.  Returns the number of iterations run.
-template <typename T, int D, typename BlockMax>
-__device__ __forceinline__ int project_set_convex_row(const T (&x0)[D], int nsets, const CSet<T> (&sets)[kMaxSets], T rho,
+template <typename T, int D, typename SetT, typename BlockMax>
+__device__ __forceinline__ int project_set_convex_row(const T (&x0)[D], int nsets, const SetT (&sets)[kMaxSets], T rho,
                                                       int max_iter, T threshold, T (&x)[D], BlockMax &&block_max)
 {
     T z[kMaxSets][kMaxSetDim], lmb[kMaxSets][kMaxSetDim];
@@ -303,7 +308,7 @@ __device__ __forceinline__ int project_set_convex_row(const T (&x0)[D], int nset
 #pragma unroll
         for (int i = 0; i < kMaxSetDim; ++i) { z[s][i] = T(0); lmb[s][i] = T(0); }
         if (s < nsets) {
-            const T *A = sets[s].A, *b = sets[s].b;
+            const auto A = sets[s].A; const auto b = sets[s].b;
             const int dim = sets[s].dim;
 #pragma unroll
             for (int i = 0; i < kMaxSetDim; ++i)
@@ -337,7 +342,7 @@ __device__ __forceinline__ int project_set_convex_row(const T (&x0)[D], int nset
 #pragma unroll
         for (int s = 0; s < kMaxSets; ++s)
             if (s < nsets) {
-                const T *A = sets[s].A, *b = sets[s].b;
+                const auto A = sets[s].A; const auto b = sets[s].b;
                 const int dim = sets[s].dim;
 #pragma unroll
                 for (int i = 0; i < kMaxSetDim; ++i)
@@ -359,7 +364,7 @@ __device__ __forceinline__ int project_set_convex_row(const T (&x0)[D], int nset
 #pragma unroll
         for (int s = 0; s < kMaxSets; ++s)
             if (s < nsets) {
-                const T *A = sets[s].A, *b = sets[s].b;
+                const auto A = sets[s].A; const auto b = sets[s].b;
                 const int dim = sets[s].dim;
                 T axb[kMaxSetDim], v[kMaxSetDim];
 #pragma unroll
@@ -411,8 +416,8 @@ __device__ __forceinline__ int project_set_convex_row(const T (&x0)[D], int nset
 
 // project_set_convex_dykstra for ONE row (isls/projections.py:465-504): every set acts on the row itself.  block_max as
 // above (one value is enough: the summed squared change of the corrections of a pass).  Returns the passes run.
-template <typename T, int D, typename BlockMax>
-__device__ __forceinline__ int dykstra_row(const T (&x0)[D], int nsets, const CSet<T> (&sets)[kMaxSets], int max_iter, T tol,
+template <typename T, int D, typename SetT, typename BlockMax>
+__device__ __forceinline__ int dykstra_row(const T (&x0)[D], int nsets, const SetT (&sets)[kMaxSets], int max_iter, T tol,
                                            T (&x)[D], BlockMax &&block_max)
 {
     T u[D], z[kMaxSets][D];
@@ -457,11 +462,11 @@ __device__ __forceinline__ int dykstra_row(const T (&x0)[D], int nsets, const CS
 }
 
 // project_soc for ONE row (isls/projections.py:163-234): A y + b in the second-order cone by ADMM.
-template <typename T, int D, typename BlockMax>
-__device__ __forceinline__ int project_soc_row(const T (&z0)[D], const CSet<T> &st, T rho, int max_iter, T tol, T (&zo)[D],
+template <typename T, int D, typename SetT, typename BlockMax>
+__device__ __forceinline__ int project_soc_row(const T (&z0)[D], const SetT &st, T rho, int max_iter, T tol, T (&zo)[D],
                                                BlockMax &&block_max)
 {
-    const T *A = st.A, *b = st.b;
+    const auto A = st.A; const auto b = st.b;
     const int dim = st.dim;
     T M[D][D], Linv[D][D], z[D], lmb[kMaxSetDim];
 #pragma unroll

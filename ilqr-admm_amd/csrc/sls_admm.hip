@@ -44,9 +44,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
         sets[s].b = p.b[s] ? p.b[s] + (int64_t)pb * p.b_sp[s] : nullptr;
         sets[s].par = p.par[s] ? p.par[s] + (int64_t)pb * p.par_sp[s] : nullptr;
     }
-#ifdef ISLS_SET_STAGE                                              // experiment, off: measured slower (see stage_sets in projections.hpp)
+#ifndef ISLS_NO_SET_STAGE                                          // set operands in LDS behind typed pointers (stage_sets_lds)
     __shared__ T set_lds[kMaxSets * kSetLdsWords];
-    stage_sets<T>(sets, p.nsets, D, set_lds);
+    CSetLds<T> lsets[kMaxSets];
+    stage_sets_lds<T>(sets, lsets, p.nsets, D, set_lds);
+#else
+    CSet<T> (&lsets)[kMaxSets] = sets;
 #endif
     // workgroup-wide max (project_set_convex: once per inner iteration) and sum (residual norms); idle threads contribute
     // zeros.  Two barriers per call (partials visible; buffer free again).  -DISLS_ONE_BARRIER builds the form with alternating
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (sizeof(T) == 4 ? (D >= 3 ? 
         T v[D], zn[D];
 #pragma unroll
         for (int c = 0; c < D; ++c) v[c] = (p.alpha * x[c] + (T(1) - p.alpha) * z[c]) + lmb[c];
-        project_set_convex_row<T, D>(v, p.nsets, sets, p.rho, p.inner_max_iter, p.threshold, zn, block_max);
+        project_set_convex_row<T, D>(v, p.nsets, lsets, p.rho, p.inner_max_iter, p.threshold, zn, block_max);
         SLS_STAMP(cyc_p)
         const T prev_prim = prim, prev_dual = dual;
         T p2 = T(0), d2 = T(0);
