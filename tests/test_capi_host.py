@@ -209,7 +209,9 @@ def test_hot_path_kernels_keep_their_registers():
             for fam in ("15sls_admm_kernelI", "19project_rows_kernelI"):
                 v = pick(f"{fam}{prec}Li{D}ELi256E")
                 (k, r), = v.items()
-                assert r["scratch"] <= (160 if prec == "f" and D >= 3 and fam.startswith("15") else 0), (k, r)
+                # the fp32 forms for rows of 3-4 entries are held to 128 registers (four wavefronts per SIMD): a bounded spill is
+                # the price (round 3: 188 B with the set operands read from LDS -- and 13-19 % faster than the 156 B form)
+                assert r["scratch"] <= (192 if prec == "f" and D >= 3 and fam.startswith("15") else 0), (k, r)
 
 
 def _exchange_rank(rank, world, port, posts, ret):
