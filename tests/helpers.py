@@ -246,12 +246,14 @@ def tassa_arrays(g, bsel, dtype=np.float64):
     return d
 
 
-def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.0, dtype="f64", outer_iters=1):
+def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.0, dtype="f64", outer_iters=1, scramble_best=None):
     """One outer DP-form iLQR-ADMM iteration through the library's own driver (`isls_ilqr_admm_outer_*`: gain pass with the
     first feed-forward pass inside, J x [ff -> rollout with the fused ADMM update]) on the device, and the same through the
     oracle's driver on the host; returns the worst relative error over K, k, the x-step, z, lambda and the residuals.
     dtype "f64" / "f32" selects isls_ilqr_admm_outer_f64 / _f32 (and the oracle of the same precision); outer_iters > 1 repeats
-    the iteration (linearise + expand, driver call, accept) so that the gain pass also sees a moved nominal."""
+    the iteration (linearise + expand, driver call, accept) so that the gain pass also sees a moved nominal.  scramble_best (a
+    seed): the `best` array the rollout reads as its PREDICTION of the winner is filled with random candidate indices first, so
+    that wavefronts with mispredicted, correctly predicted and mixed winners all occur (recorded winner vs replay)."""
     import torch
     f = np.float64 if dtype == "f64" else np.float32
     o = OracleDriver(oracle_kern, problem_arrays(cfg, bsel, dtype=f), rho_u=rho_u, relax=relax, dtype=f)
@@ -274,8 +276,10 @@ def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.
                         status=h.status, active=h.admm_active)
     admm = K.admm_args(h.xx, h.xu, h.res, zu=h.zu, lu=h.lu, u_lo=pa["u_lo"], u_hi=pa["u_hi"], relax=h.relax, tol_abs=0.0,
                        tol_rel=0.0, res_prev=h.res_prev, active=h.admm_active)
-    for _ in range(outer_iters):
+    for it_ in range(outer_iters):
         h.linearize_expand()
+        if scramble_best is not None:
+            h.best.copy_(torch.from_numpy(np.random.default_rng(scramble_best + it_).integers(0, L, size=B).astype(np.int32)))
         hip.outer(gain, ff, ro, admm, J, dtype, outer_active=h.outer_active)
         hip.accept_step(h.xx, h.xu, h.cost_new, h.xhat, h.uhat, h.cost, outer_active=h.outer_active)
     torch.cuda.synchronize()

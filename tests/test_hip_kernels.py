@@ -684,6 +684,19 @@ def test_outer_driver_both_precisions(oracle, B, J, L, dtype, tol):
     assert err < tol, f"{dtype}: {err:.2e}"
 
 
+@pytest.mark.parametrize("B,L", [(33, 20), (7, 5), (10, 33)])
+def test_outer_driver_with_mispredicted_winners(oracle, B, L):
+    """The rollout records the controls of the candidate `best` names at launch (the previous winner) and replays the winner
+    only where that prediction fails.  With `best` scrambled before every outer iteration the wavefronts hold trajectories whose
+    prediction hits (recorded u_t, x_t from the checkpoints), trajectories whose prediction misses (winner replay) and both:
+    every one of them must give the oracle's x-step, z, lambda and residuals, whatever its neighbours in the wavefront do."""
+    from dual import hip_kernels
+    from helpers import outer_iteration_on_device
+    cfg = P.config2(batch=B, N=100, seed=11)
+    err = outer_iteration_on_device(cfg, range(B), hip_kernels(), oracle, L, 3, cfg["rho_u"], cfg["relax"], outer_iters=2, scramble_best=5)
+    assert err < 1e-10, f"{err:.2e}"
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_state_independent_linearisation_patterns(oracle, dtype):
     """`isls_linearize_*` for the models whose Jacobians do not depend on the state (dense LTI, double integrator): the

@@ -36,7 +36,9 @@ def main():
         J = int(rng.integers(1, 5))
         seed = int(rng.integers(0, 1000))
         cfg = P.config2(batch=B, N=N, seed=seed)
-        err = outer_iteration_on_device(cfg, range(B), hip, okern, L, J, cfg["rho_u"], cfg["relax"])
+        # every other case starts from a scrambled prediction of the line-search winner (recorded winner vs replay, mixed wavefronts)
+        err = outer_iteration_on_device(cfg, range(B), hip, okern, L, J, cfg["rho_u"], cfg["relax"], outer_iters=1 + c % 2,
+                                        scramble_best=(seed if c % 2 else None))
         print(f"case {c:3d}: B={B:3d} N={N:3d} L={L:2d} J={J} seed={seed:3d}  err {err:.2e}", flush=True)
         if not (err <= worst):
             worst, worst_case = err, (B, N, L, J, seed)
