@@ -102,8 +102,11 @@ __device__ __forceinline__ bool chol_upper_rd(const T (&A)[M][M], T (&U)[M][M], 
 // trajectory of their own are therefore exact copies: surplus lanes of the wavefront repeat its last lane, and a slot whose
 // trajectory is past the batch or inactive shadows the first valid trajectory of the wavefront (same loads, same
 // arithmetic, same stores to the same addresses; only the record image keeps the slot's own place).
+#ifndef ISLS_GAIN_OCC
+#define ISLS_GAIN_OCC 1
+#endif
 template <typename T, int NX, int NU, int D, int MODE, bool FF, bool REC, bool ARR>
-__global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
+__global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T> p)
 {
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
     constexpr int V_OFF = 0, AB_OFF = V_OFF + NX * NX, Q_OFF = AB_OFF + NX * W, K_OFF = Q_OFF + NU * W;
@@ -485,12 +488,24 @@ __global__ __launch_bounds__(64) void riccati_gain_kernel(GainP<T> p)
         }
         const int64_t o = bN + t;
         // the lane's column of [Phi | B]: x-lane i -> Phi[:, i] = A[:, i] + B K[:, i]; u-lane r -> B[:, r] (its K column is zero)
+#ifndef ISLS_GAIN_REREAD_B
+#define ISLS_GAIN_REREAD_B 1
+#endif
+        // B_t comes from the slot's LDS again here instead of staying in registers since (2): 36 registers less across the
+        // factorisation (the compiler parks what does not fit in AGPRs and copies it back)
+        T Bq[NX][NU];
+        if constexpr (ISLS_GAIN_REREAD_B) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k)
+#pragma unroll
+                for (int r = 0; r < NU; ++r) Bq[k][r] = ABs[k * W + NX + r];
+        }
         T phc[NX];
         static_for<NX>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
             T ph = colv[k];
 #pragma unroll
-            for (int r = 0; r < NU; ++r) ph += Fr[k][NX + r] * Kc[r];
+            for (int r = 0; r < NU; ++r) ph += (ISLS_GAIN_REREAD_B ? Bq[k][r] : Fr[k][NX + r]) * Kc[r];
             phc[k] = ph;
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, 2 * NX + k>{});
         });
