@@ -489,10 +489,11 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
         const int64_t o = bN + t;
         // the lane's column of [Phi | B]: x-lane i -> Phi[:, i] = A[:, i] + B K[:, i]; u-lane r -> B[:, r] (its K column is zero)
 #ifndef ISLS_GAIN_REREAD_B
-#define ISLS_GAIN_REREAD_B 1
+#define ISLS_GAIN_REREAD_B 0
 #endif
-        // B_t comes from the slot's LDS again here instead of staying in registers since (2): 36 registers less across the
-        // factorisation (the compiler parks what does not fit in AGPRs and copies it back)
+        // (-DISLS_GAIN_REREAD_B=1: B_t from the slot's LDS again here instead of registers kept since (2): 402 -> 394 registers,
+        // no faster with the feed-forward pass inside (208-213 us both) and 6 us slower without (172 vs 166 us); capping the
+        // kernel at 256 registers -- -DISLS_GAIN_OCC=2 -- spills 456 B into scratch and takes 385 us: its real pressure is ~370)
         T Bq[NX][NU];
         if constexpr (ISLS_GAIN_REREAD_B) {
 #pragma unroll
