@@ -270,3 +270,18 @@ def test_table_exchange_single_rank_needs_no_process_group():
         t = xch.post(lambda table, r, i=i: table.copy_(torch.full((1, 5), float(i), dtype=torch.float64)))
         assert float(t[0, 0]) == i
     assert float(xch.latest(lag=1)[0, 0]) == 1.0 and float(xch.finish()[0, 0]) == 2.0
+
+
+def test_bench_byte_formulas():
+    """bench.py's algorithmic byte counts: the SURVEY 8(d) figure with z, lambda counted for the constrained blocks only (config 2
+    constrains u alone: 373.6 MB per outer iteration with the batch-shared Hessian tables), and the per-kernel
+    figures the roofline fractions are quoted against."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    n, m, N, w, B = 6, 3, 100, 8, 4096
+    assert b.iteration_bytes(n, m, N, w, True, has_x=False, has_u=True) * B == 373_555_200
+    assert b.iteration_bytes(n, m, N, w, False, has_x=True, has_u=True) == w * N * (2 * n * n + 2 * n * m + m * m + m + 7 * (n + m))   # 146 400 B
+    gain, ff, ro, admm, prep = b.algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=False, hess_shared=True, records=True, gain_ff=True)
+    assert ro * B == 147_456_000 and ff * B == 334_233_600 and gain * B == 304_742_400
