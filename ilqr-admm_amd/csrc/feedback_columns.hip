@@ -441,6 +441,14 @@ __global__ __launch_bounds__(64) void columns_step_kernel(int N, int n, int m, c
     for (int e = threadIdx.x; e < N * n; e += kWave) dx0[ox + e] = x_out[ox + e] - xhat[ox + e];
 }
 
+// flag <- 1 when a problem of the batch is still active (flag zeroed by the caller of this kernel)
+__global__ __launch_bounds__(256) void any_active_kernel(int B, const int32_t *active, int32_t *flag)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = b < B && active[b] != 0;
+    if (__ballot(on) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 template <typename T>
 int launch_columns_iteration(const isls_columns_iteration_args &a, hipStream_t s)
 {
@@ -488,6 +496,12 @@ int launch_columns_iteration(const isls_columns_iteration_args &a, hipStream_t s
         if ((rc = launch_columns_admm<T>(z, s)) != ISLS_OK) return rc;
         if (a.log && hipMemcpyAsync(a.log, a.admm.res, sizeof(T) * (size_t)B * 2, hipMemcpyDeviceToDevice, s) != hipSuccess)
             return ISLS_ERR_LAUNCH;
+    }
+    if (a.any_active) {
+        if (!a.admm.active) return ISLS_ERR_ARG;
+        if (hipMemsetAsync(a.any_active, 0, sizeof(int32_t), s) != hipSuccess) return ISLS_ERR_LAUNCH;
+        hipLaunchKernelGGL(any_active_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, (const int32_t *)a.admm.active, a.any_active);
+        if ((rc = check_launch()) != ISLS_OK) return rc;
     }
     return ISLS_OK;
 }

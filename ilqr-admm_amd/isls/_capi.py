@@ -174,7 +174,8 @@ class OuterArgs(C.Structure):
 
 class ColumnsIterationArgs(C.Structure):
     _fields_ = [("ff", FfArgs), ("cols", ColumnsArgs), ("ls", RolloutArgs), ("admm", ColumnsAdmmArgs),
-                ("proj_x", C.c_void_p), ("proj_u", C.c_void_p), ("zero_x", C.c_void_p), ("zero_u", C.c_void_p), ("log", C.c_void_p)]
+                ("proj_x", C.c_void_p), ("proj_u", C.c_void_p), ("zero_x", C.c_void_p), ("zero_u", C.c_void_p), ("log", C.c_void_p),
+                ("any_active", C.c_void_p)]
 
 
 class AdvanceArgs(C.Structure):

@@ -251,9 +251,10 @@ class Engine:
             self.u_lo = self.u_hi = None
 
     # ---- single kernels -----------------------------------------------------------------------------------
-    def evaluate_cost(self):
+    def evaluate_cost(self, out=None):
+        """cost of the nominal into `out` (default: self.cost); also refreshes c0x, c0u about it"""
         self.kern.expand_quadratic(self.Qtab, self.ztab, self.seq, self.u_std, self.c0x, self.c0u,
-                                   xhat=self.xhat, uhat=self.uhat, cost=self.cost, cost_model=self.cost_model,
+                                   xhat=self.xhat, uhat=self.uhat, cost=self.cost if out is None else out, cost_model=self.cost_model,
                                    cost_par=self.cost_par, q_nonzero=self.q_nonzero, stream=_stream_ptr())
 
     def linearize(self):

@@ -234,6 +234,14 @@ class _LaggedAny:
         e.record()
         self.ev.append(e)
 
+    def push_flag(self, flag):
+        """the same with a one-word device flag somebody else has computed (isls_columns_iteration_args.any_active)"""
+        i = len(self.ev)
+        self.host[i:i + 1].copy_(flag, non_blocking=True)
+        e = torch.cuda.Event()
+        e.record()
+        self.ev.append(e)
+
     def seen_all_inactive(self):
         """True when a flag that has already arrived says that no problem was active after its iteration."""
         for i, e in enumerate(self.ev):
@@ -295,6 +303,7 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
     drv = dict(args=None, ptrs=None)
     host_sync = self._host_ls or self._host_cost or not device_only or verbose   # host callbacks need the numbers anyway
     outer_count = torch.zeros(B, dtype=torch.int32, device=e.device)
+    flags = torch.ones(max(1, J), dtype=torch.int32, device=e.device)          # "a problem is still active" behind every ADMM iteration
     outer_lag = _LaggedAny(e.device, int(k_max))
     inner_lag = _LaggedAny(e.device, J)
     ran = 0
@@ -343,34 +352,36 @@ def isls_admm(self, dim, get_AB=None, get_Cs=None, project_x=False, project_u=Fa
         for j in range(J):
             if use_driver:
                 drv["args"].log = logbuf[j].data_ptr() if cs.constrained else None
+                drv["args"].any_active = flags[j:j + 1].data_ptr() if cs.constrained else None
                 e.kern.columns_iteration(drv["args"], e.sfx, stream=_stream_ptr())
             else:
                 admm_iteration()
             if not cs.constrained:
                 e.admm_iters.add_(act)
                 break
-            if not use_driver:
+            if use_driver:
+                inner_lag.push_flag(flags[j:j + 1])
+            else:
                 logbuf[j].copy_(e.res)
-            inner_lag.push(act)
+                inner_lag.push(act)
             if inner_lag.seen_all_inactive():
                 break
         # new nominal: x_nom + d_x, u_nom + d_u of the last x-step (isls.py:684-687); the setter evaluates its cost
-        oa = mask3(e.outer_active)
-        e.xhat.copy_(torch.where(oa, e.xhat + dx[0], e.xhat))
-        e.uhat.copy_(torch.where(oa, e.uhat + du[0], e.uhat))
-        e.evaluate_cost()
+        oa = e.outer_active.to(e.dtype).view(B, 1, 1)
+        e.xhat.addcmul_(dx[0], oa)                                              # x_nom + d_x where the problem still iterates
+        e.uhat.addcmul_(du[0], oa)
+        # cost log entry of this outer iteration and the two stop rules (|cost - prev| < 1e-4, isls.py:695-697; oscillation of
+        # the last eight costs < 1e-3, isls.py:699-701) on the device: isls_accept_step with the nominal as its own x-step;
+        # e.cost still holds the cost before this iteration (`prev` of the rule), the new one goes to cost_new
+        e.evaluate_cost(out=e.cost_new)
         if self._host_cost:
             self._refresh_host_cost()
+            e.cost_new.copy_(e.cost)
+            e.cost.copy_(costlog[k])
         ran = k + 1
-        # cost log entry of this outer iteration and the two stop rules (|cost - prev| < 1e-4, isls.py:695-697; oscillation of
-        # the last eight costs < 1e-3, isls.py:699-701) on the device: isls_accept_step with the nominal as its own x-step
-        e.cost_new.copy_(e.cost)
-        e.cost.copy_(costlog[k])                                                # `prev` of the rule: the cost before this iteration
-        e.cost.copy_(torch.where(e.outer_active.to(torch.bool), e.cost, e.cost_new))
         costlog[k + 1].copy_(e.cost_new)
         e.kern.accept_step(e.xhat, e.uhat, e.cost_new, e.xhat, e.uhat, e.cost, cost_hist=e.cost_hist, hist_len=e.hist_len,
                            tol_cost=1e-4, tol_osc=1e-3, outer_active=e.outer_active, stream=_stream_ptr())
-        e.cost.copy_(e.cost_new)
         outer_lag.push(e.outer_active)
         if host_sync:
             st = e.status.cpu().numpy()

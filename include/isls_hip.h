@@ -494,7 +494,7 @@ int isls_columns_admm_f32(const isls_columns_admm_args *a, void *stream);
  *              problems (isls.py:593-606);
  *   z-step   : isls_columns_admm phase 0, the row projections (proj_x / proj_u, nullable: block absent), phase 1 (`admm`;
  *              skipped when both blocks are absent: the unconstrained problem has no z-step);
- *   `log`    : nullable [B,2], receives admm.res behind the z-step.
+ *   `log`    : nullable [B,2], receives admm.res behind the z-step;  `any_active`: see the field.
  * Nothing is exchanged with the host between the launches.
  * ------------------------------------------------------------------------------------------- */
 typedef struct isls_columns_iteration_args {
@@ -505,6 +505,9 @@ typedef struct isls_columns_iteration_args {
     const isls_project_args *proj_x, *proj_u;
     const void *zero_x, *zero_u;    /* [n], [m] zeros (cost gradients of the columns >= 1 in the one-pass-per-column form) */
     void *log;
+    int32_t *any_active;            /* nullable: one word, set to 1 when admm.active still holds a problem behind the z-step, else 0 --
+                                     * the flag a host loop follows (copied to pinned memory, read when it has landed) instead of
+                                     * reducing the mask itself */
 } isls_columns_iteration_args;
 
 int isls_columns_iteration_f64(const isls_columns_iteration_args *a, void *stream);
