@@ -39,6 +39,14 @@ class iSLS(Base):
         self._user_AB = False
         self._host_model = self._host_cost = False              # plain Python callables: the line search runs on the host
 
+    @property
+    def _dx_columns(self):
+        """[d_x, phi_x] rows [B, N n, 1 + dim] of the last `isls_admm` x-step, copied from the device on first use"""
+        if getattr(self, "_dx_columns_host", None) is None and getattr(self, "_dx_columns_dev", None) is not None:
+            from .robust import ColumnSolver
+            self._dx_columns_host = ColumnSolver.rows_to_host(self._dx_columns_dev)
+        return getattr(self, "_dx_columns_host", None)
+
     # ---- setters / getters (isls/isls_base.py:74-158) ------------------------------------------------------
     @property
     def forward_model(self):
