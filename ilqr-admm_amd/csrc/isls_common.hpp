@@ -186,7 +186,12 @@ __device__ __forceinline__ float py_mod(float a, float b)
 // Words between the packed step records [A+BK | B | K | fac] of consecutive trajectories of a wavefront (isls_gain_args.rec):
 // the record padded to an even word count, so that the feed-forward pass fetches records as aligned 16-byte pairs that
 // never straddle two trajectories.
-__host__ __device__ constexpr int rec_stride(int n, int m) { return (n * n + 2 * n * m + m * m + 1) & ~1; }
+// rec_model_words: words behind fac that describe the step's linearisation for the model-structured feed-forward form
+// (isls_ff_args.lin_on).  The pair (9, 3) carries the six words A[6:8, 0:3] -- the Jacobian rows of ISLS_MODEL_ARM3R, from which
+// its A and B follow -- so that pass reads one contiguous tail [K | fac | J] instead of gathering J from the A array (scattered
+// 8-byte loads at a 64.8 KB stride: the structured form then ran no faster than the dense one).  Other pairs: none.
+__host__ __device__ constexpr int rec_model_words(int n, int m) { return (n == 9 && m == 3) ? 6 : 0; }
+__host__ __device__ constexpr int rec_stride(int n, int m) { return (n * n + 2 * n * m + m * m + rec_model_words(n, m) + 1) & ~1; }
 
 // Launch wrappers implemented one per .hip file; each returns ISLS_OK / ISLS_ERR_*.
 // ff != nullptr: the pass may also run the first feed-forward pass (same records, time-invariant Qr / Rr); *did_ff tells

@@ -558,6 +558,11 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
         for (int k = 0; k < NX; ++k) imq[r_b1 + k * r_s1] = phc[k];
 #pragma unroll
         for (int c = 0; c < NU; ++c) imq[r_b2 + c * r_s2] = tail[c];
+        if constexpr (REC && rec_model_words(NX, NU) == 6) {
+            // A[6:8, 0:3] of the step behind fac (rec_model_words): lanes 0..5 of a slot carry one word each, the others word 0 again
+            const int je = i < 6 ? i : 0;
+            imq[s * RW + RFAC + NU * NU + je] = ABs[(6 + je / 3) * W + je % 3];
+        }
         if constexpr (ARR) {
             {
                 // cooperative store of [Qux Quu] rows and the factor (skipped when the caller only wants K and the packed

@@ -43,6 +43,9 @@ struct FfRecP {
     int rev;                       // 1: the grid walks the trajectory blocks from the last to the first (see launch_ff_record)
     const T *Qr_term;              // nullable: weight block of the terminal step (isls_ff_args.Qr_term), batch stride Qr.sb
     int ncol;                      // feedback columns in one launch (blockIdx.z): zx, lx, zu, lu, k, vseg hold ncol blocks, c0 acts on column 0
+    // model-structured form (isls_ff_args.lin_on): only [K | fac] of a record is read; A'v and B'v come from the model
+    const T *lin_par;              // model parameters (isls_linearize_args.model_par), batch stride lin_par_sb
+    int64_t lin_par_sb;
 };
 
 // FG: ring entries are refilled in groups of FG consecutive steps -- one burst of FG records (FG x 648 B at n=6, m=3) per
@@ -259,13 +262,33 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
 //     last lane, slots without a trajectory shadow the first valid one, every lane of a slot stores an entry of k_t), so
 //     the compiler's vmcnt bookkeeping stays exact and D steps of records really are in flight.
 // The sums are those of riccati_ffrec_kernel in the same order: results are bit-identical to it.
-template <typename T, int NX, int NU, int D, int OCC, int MODE>
+// LIN (isls_ff_args.lin_on): 0 = the whole record, Phi'v from its [Phi | B] block.  Otherwise A and B are the linearisation of a
+// built-in model whose structure the pass knows, so it reads only the [K | fac] tail of every record (27 of 81 words at n = 6,
+// m = 3; 42 of 150 at n = 9, J included) and evaluates  Phi'v = A'v + K'(B'v)  with
+//   LIN_DI    (ISLS_MODEL_DI):    A = [I aI; 0 I], B = [b0 I; b1 I]:  (A'v)_i = v_i (+ a v_{i-d}),  (B'v)_r = b0 v_r + b1 v_{d+r}
+//   LIN_ARM3R (ISLS_MODEL_ARM3R): A = [I dtI 0; 0 I 0; J dtJ 0], B = [hI; dtI; hJ], h = dt^2/2, J = A[6:8, 0:3] (6 words per step,
+//             which the gain pass puts behind fac: rec_model_words):  jv = J'v_ee,  (A'v)_q = v_q + jv,  (A'v)_qd = dt (v_q + jv) + v_qd,  (A'v)_ee = 0,
+//             B'v = h (v_q + jv) + dt v_qd
+// -- the same products as the dense form in another association (results equal up to rounding, same tolerance against the oracle).
+constexpr int LIN_NONE = 0, LIN_DI = 1, LIN_ARM3R = 2;
+
+template <typename T, int NX, int NU, int D, int OCC, int MODE, int LIN = LIN_NONE>
 __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
 {
+    static_assert(LIN != LIN_DI || NX == 2 * NU, "double integrator: n = 2 d, m = d");
+    static_assert(LIN != LIN_ARM3R || (NX == 9 && NU == 3), "planar 3R arm: n = 9, m = 3");
+    constexpr bool LEAN = LIN != LIN_NONE;
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
-    constexpr int PHI_OFF = 0, B_OFF = PHI_OFF + NX * NX, K_OFF = B_OFF + NX * NU, FAC_OFF = K_OFF + NU * NX, RW = rec_stride(NX, NU);
-    // slot: record | d[W] | c0u[NU] | v[NX] | qu[NU] | dump pair
-    constexpr int D_OFF = RW, C0U_OFF = D_OFF + W, V_OFF = C0U_OFF + NU, QU_OFF = V_OFF + NX, DUMP_OFF = (QU_OFF + NU + 1) & ~1;
+    constexpr int RW = rec_stride(NX, NU);                     // words between the records of consecutive slots in HBM
+    constexpr int SRC_OFF = LEAN ? NX * NX + NX * NU : 0;      // first word of a record the pass reads (even: 16-byte pairs)
+    constexpr int NJ = LIN == LIN_ARM3R ? 6 : 0;               // the arm's J behind fac (rec_model_words)
+    static_assert(NJ <= rec_model_words(NX, NU), "the records of this pair carry no model words");
+    constexpr int SW = LEAN ? ((NU * NX + NU * NU + NJ + 1) & ~1) : RW;   // words of a record staged through LDS
+    static_assert(SRC_OFF % 2 == 0 && SRC_OFF + SW <= RW, "record tail must be pair-aligned and inside the record");
+    constexpr int PHI_OFF = 0, B_OFF = PHI_OFF + NX * NX, K_OFF = LEAN ? 0 : B_OFF + NX * NU, FAC_OFF = K_OFF + NU * NX;
+    constexpr int J_OFF = FAC_OFF + NU * NU;
+    // slot: record (tail: K | fac | J) | d[W] | c0u[NU] | v[NX] | qu[NU] | dump pair
+    constexpr int D_OFF = SW, C0U_OFF = D_OFF + W, V_OFF = C0U_OFF + NU, QU_OFF = V_OFF + NX, DUMP_OFF = (QU_OFF + NU + 1) & ~1;
     constexpr int SLOT = DUMP_OFF + 2;                         // even: every slot's record starts on a 16-byte boundary
     __shared__ __align__(16) T lds[(TPW + 1) * SLOT];
     typedef T V2 __attribute__((ext_vector_type(2)));
@@ -295,15 +318,16 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     // records: blocked by wavefront, [block][t][slot][RW]; lane l fetches the 16-byte pairs l, l+64, ... of the step's run.
     // A slot that shadows another trajectory still reads its own place in the run (whatever the gain pass left there) but
     // restages the shadowed slot's record below, so it computes exactly what that slot computes.
-    constexpr int BW = TPW * RW, NP = BW / 2, JR = (NP + kWave - 1) / kWave;
+    constexpr int BW = TPW * RW, NP = TPW * SW / 2, JR = (NP + kWave - 1) / kWave;
     const T *bR = p.rec + (int64_t)bx * N * BW;
     uint32_t oR[JR];
     int dR[JR];
 #pragma unroll
     for (int j = 0; j < JR; ++j) {
-        const int w = 2 * (lane + kWave * j);
-        oR[j] = (uint32_t)(w < BW ? w : BW - 2);
-        dR[j] = w < BW ? (w / RW) * SLOT + (w % RW) : TPW * SLOT + DUMP_OFF;
+        const int q = lane + kWave * j;
+        const int w = 2 * (q < NP ? q : NP - 1);               // word within the staged words of the wavefront's slots
+        oR[j] = (uint32_t)((w / SW) * RW + SRC_OFF + (w % SW));
+        dR[j] = q < NP ? (w / SW) * SLOT + (w % SW) : TPW * SLOT + DUMP_OFF;
     }
     // where this lane READS its slot's record: its own slot, or the shadowed one
     const int ssh = (bb - bx * TPW);                   // slot of the trajectory the lane computes (== s when valid)
@@ -329,6 +353,15 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
         for (int c = 0; c < NU; ++c) rr2[r][c] = hasu ? T(2) * p.Rr.at(bb, 0)[r * NU + c] : T(0);
     }
     const T xmask = xl ? T(1) : T(0);
+    // structured forms: (A'v)_i = v_i * sown + cv * v_o + cj * jv_o with lane constants; w = B'v by every lane
+    const T *lpar = LEAN ? p.lin_par + (int64_t)bb * p.lin_par_sb : nullptr;
+    T la = T(0), lb0 = T(0), lb1 = T(0), ldt = T(0), lh = T(0);
+    if constexpr (LIN == LIN_DI) { la = lpar[0]; lb0 = lpar[1]; lb1 = lpar[2]; }
+    if constexpr (LIN == LIN_ARM3R) { ldt = lpar[0]; lh = T(0.5) * (ldt * ldt); }
+    const int lo = LIN == LIN_DI ? ((xl && i >= NU) ? i - NU : 0) : ((xl && i < 6) ? i % 3 : 0);   // the other entry of v the lane needs
+    const T sown = LIN == LIN_ARM3R ? ((xl && i < 6) ? T(1) : T(0)) : T(1);
+    const T cv = LIN == LIN_DI ? ((xl && i >= NU) ? la : T(0)) : ((xl && i >= 3 && i < 6) ? ldt : T(0));
+    const T cj = LIN == LIN_ARM3R ? ((xl && i < 3) ? T(1) : ((xl && i < 6) ? ldt : T(0))) : T(0);
 
     struct Stage {
         V2 rr[JR];
@@ -350,7 +383,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     const int d_dst = D_OFF + i;                               // own d component (x-lanes: d_x[i]; u-lanes: d_u[r] at D_OFF + NX + r)
     const int c_dst = xl ? DUMP_OFF : C0U_OFF + iu;            // u-lanes publish c0u_r
     const int o_dst = xl ? V_OFF + i : QU_OFF + iu;            // x-lanes publish v_i, u-lanes qu_r
-    const int cbase = xl ? PHI_OFF + i : B_OFF + iu, cstr = xl ? NX : NU;   // own column of [Phi | B]
+    const int cbase = xl ? PHI_OFF + i : B_OFF + iu, cstr = xl ? NX : NU;   // own column of [Phi | B] (dense form)
     const int ic = xl ? i : 0;
     const int ku = xl ? i % NU : iu;                           // the entry of k this lane stores (x-lanes: copies)
     T *const kbase = p.k + ((int64_t)col * p.B + bb) * N * NU + ku;
@@ -403,8 +436,19 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
             fetch(t - D > t_lo ? t - D : t_lo, g);             // refill (clamped, unconditional)
             // ---- one batch of reads ----
             T dx[NX], du[NU], c0u[NU], col[NX], vv[NX], kcol[NU], facn[NU][NU], qup[NU];
+            T v_own = T(0), v_oth = T(0), jm[NJ > 0 ? NJ : 1];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) { dx[j] = rrec[D_OFF + j]; col[j] = rrec[cbase + j * cstr]; vv[j] = rrec[V_OFF + j]; }
+            for (int j = 0; j < NX; ++j) {
+                dx[j] = rrec[D_OFF + j];
+                vv[j] = rrec[V_OFF + j];
+                if constexpr (!LEAN) col[j] = rrec[cbase + j * cstr];
+            }
+            if constexpr (LEAN) {
+                v_own = rrec[V_OFF + ic];
+                v_oth = rrec[V_OFF + lo];
+#pragma unroll
+                for (int e = 0; e < NJ; ++e) jm[e] = rrec[J_OFF + e];
+            }
 #pragma unroll
             for (int r = 0; r < NU; ++r) {
                 du[r] = rrec[D_OFF + NX + r]; c0u[r] = rrec[C0U_OFF + r]; kcol[r] = rrec[K_OFF + r * NX + ic]; qup[r] = rrec[QU_OFF + r];
@@ -427,14 +471,39 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
             T ci = c0_own + sx;                                // x-lanes: cx_i
 #pragma unroll
             for (int r = 0; r < NU; ++r) ci = (!xl && iu == r) ? cu[r] : ci;
-            T acc = T(0);
+            T qi, vnew;
+            if constexpr (!LEAN) {
+                T acc = T(0);
 #pragma unroll
-            for (int k = 0; k < NX; ++k) acc += col[k] * vv[k];
-            const T qi = ci + acc;                             // x-lanes: cx_i + (Phi'v)_i; u-lanes: qu_r
-            T kcu = T(0);
+                for (int k = 0; k < NX; ++k) acc += col[k] * vv[k];
+                qi = ci + acc;                                 // x-lanes: cx_i + (Phi'v)_i; u-lanes: qu_r
+                T kcu = T(0);
 #pragma unroll
-            for (int r = 0; r < NU; ++r) kcu += kcol[r] * cu[r];
-            const T vnew = qi + kcu;
+                for (int r = 0; r < NU; ++r) kcu += kcol[r] * cu[r];
+                vnew = qi + kcu;
+            } else {
+                T w[NU], jvo = T(0);                           // w = B'v; jvo = (J'v_ee)_o of the lane's own o
+                if constexpr (LIN == LIN_DI) {
+#pragma unroll
+                    for (int r = 0; r < NU; ++r) w[r] = lb0 * vv[r] + lb1 * vv[NU + r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NU; ++r) {
+                        const T jv = jm[r] * vv[6] + jm[3 + r] * vv[7];
+                        w[r] = lh * (vv[r] + jv) + ldt * vv[3 + r];
+                        jvo = (lo == r) ? jv : jvo;
+                    }
+                }
+                const T atv = (sown * v_own + cv * v_oth) + cj * jvo;      // x-lanes: (A'v)_i
+                T wu = w[0];
+#pragma unroll
+                for (int r = 1; r < NU; ++r) wu = (iu == r) ? w[r] : wu;
+                qi = ci + (xl ? atv : wu);                     // x-lanes: cx_i + (A'v)_i; u-lanes: qu_r = cu_r + (B'v)_r
+                T kq = T(0);
+#pragma unroll
+                for (int r = 0; r < NU; ++r) kq += kcol[r] * (cu[r] + w[r]);   // (K' qu)_i = (K'cu)_i + (K'B'v)_i
+                vnew = qi + kq;
+            }
             vcur = live ? vnew : vcur;
             // k of the previous step from its cached factor and qu (this step's hand-off delivered qu)
             T kt[NU];
@@ -509,6 +578,34 @@ static bool v2_on_()
     return on;
 }
 
+#ifndef ISLS_FF2_LEAN_DEPTH
+#define ISLS_FF2_LEAN_DEPTH 3      // ring depth of the model-structured form (a third of the record words per entry)
+#endif
+static bool lean_on_()
+{
+    static const bool on = [] { const char *e = getenv("ISLS_FF_LEAN"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
+// the one-hand-off kernel in the form `lin` selects (the structured forms exist for the dimensions their models have)
+template <typename T, int NX, int NU, int D, int DL, int OCC, int MODE>
+static void launch_ffrec2(int lin, dim3 grid, hipStream_t s, const FfRecP<T> &p)
+{
+    if constexpr (NX == 2 * NU) {
+        if (lin == LIN_DI) {
+            hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX, NU, DL, OCC, MODE, LIN_DI>), grid, dim3(64), 0, s, p);
+            return;
+        }
+    }
+    if constexpr (NX == 9 && NU == 3) {
+        if (lin == LIN_ARM3R) {
+            hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX, NU, DL, OCC, MODE, LIN_ARM3R>), grid, dim3(64), 0, s, p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX, NU, D, OCC, MODE, LIN_NONE>), grid, dim3(64), 0, s, p);
+}
+
 template <typename T>
 int launch_ff_record(const isls_ff_args &a, hipStream_t s)
 {
@@ -539,10 +636,22 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
 #define ISLS_FF2_SEG_DEPTH 2
 #endif
     const bool v2_on = v2_on_();
+    // model-structured form (isls_ff_args.lin_on): a hint -- the records are complete, so every case the one-hand-off kernel
+    // does not take (time-varying weights, ISLS_FF_V2 = 0, ISLS_FF_LEAN = 0) runs the dense form; a request that contradicts
+    // itself is an error
+    int lin = LIN_NONE;
+    if (a.lin_on) {
+        if (a.lin_model == ISLS_MODEL_DI) { if (a.n != 2 * a.m) return ISLS_ERR_ARG; lin = LIN_DI; }
+        else if (a.lin_model == ISLS_MODEL_ARM3R) { if (a.n != 9 || a.m != 3) return ISLS_ERR_ARG; lin = LIN_ARM3R; }
+        else return ISLS_ERR_UNSUPPORTED;
+        if (!a.lin_par) return ISLS_ERR_ARG;
+        if (!(rowc && v2_on && lean_on_())) lin = LIN_NONE;
+    }
+    p.lin_par = (const T *)a.lin_par; p.lin_par_sb = a.lin_par_sb;
 #define LAUNCH2(NX_, NU_, MODE_)                                                                                        \
     {                                                                                                                   \
-        if (segmented) hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEG_DEPTH, (NX_ * NX_ > 64 ? 1 : 2), MODE_>), dim3(grid, p.nseg, p.ncol), dim3(64), 0, s, p); /* n = 9: 256 registers spill */ \
-        else hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX_, NU_, ISLS_FF2_SEQ_DEPTH, 1, MODE_>), dim3(grid, 1, p.ncol), dim3(64), 0, s, p);      \
+        if (segmented) launch_ffrec2<T, NX_, NU_, ISLS_FF2_SEG_DEPTH, ISLS_FF2_SEG_DEPTH, (NX_ * NX_ > 64 ? 1 : 2), MODE_>(lin, dim3(grid, p.nseg, p.ncol), s, p); /* n = 9: 256 registers spill */ \
+        else launch_ffrec2<T, NX_, NU_, ISLS_FF2_SEQ_DEPTH, ISLS_FF2_LEAN_DEPTH, 1, MODE_>(lin, dim3(grid, 1, p.ncol), s, p);                  \
     }
 #define CALL(NX_, NU_)                                                                                                  \
     {                                                                                                                   \

@@ -17,7 +17,7 @@ try:  # torch is plumbing (device memory, streams); the binding itself works on 
 except Exception:  # pragma: no cover
     torch = None
 
-ABI_VERSION = 105            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
+ABI_VERSION = 106            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
@@ -54,7 +54,8 @@ class FfArgs(C.Structure):
                 ("xhat", C.c_void_p), ("uhat", C.c_void_p),
                 ("zx", C.c_void_p), ("lx", C.c_void_p), ("zu", C.c_void_p), ("lu", C.c_void_p),
                 ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
-                ("k", C.c_void_p), ("active", C.c_void_p), ("seg", FfSeg), ("rec", C.c_void_p), ("Qr_term", C.c_void_p)]
+                ("k", C.c_void_p), ("active", C.c_void_p), ("seg", FfSeg), ("rec", C.c_void_p), ("Qr_term", C.c_void_p),
+                ("lin_on", C.c_int32), ("lin_model", C.c_int32), ("lin_par", C.c_void_p), ("lin_par_sb", C.c_int64)]
 
 
 class FfPrepareArgs(C.Structure):
@@ -293,7 +294,8 @@ def _dense(x, shape, name):
 def ff_record_elems(B, N, n, m):
     """isls_ff_record_elems: elements of the packed-record buffer of the gain pass (blocked by wavefront)."""
     tpw = 64 // (n + m)
-    return -(-B // tpw) * tpw * N * ((n * n + 2 * n * m + m * m + 1) & ~1)       # record stride padded to an even word count
+    model_words = 6 if (n, m) == (9, 3) else 0                 # rec_model_words (csrc/isls_common.hpp): the arm's A[6:8, 0:3] behind fac
+    return -(-B // tpw) * tpw * N * ((n * n + 2 * n * m + m * m + model_words + 1) & ~1)   # record stride padded to an even word count
 
 
 def _record(rec, B, N, n, m):
@@ -383,9 +385,18 @@ class Kernels:
 
     @staticmethod
     def ff_args(A, Bm, c0x, c0u, K, Quu, fac, Qux, k, Qr=None, Rr=None, xhat=None, uhat=None,
-                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None, seg=None, rec=None, ncol=1, Qr_term=None):
+                zx=None, lx=None, zu=None, lu=None, solve_mode=SOLVE_CHOL, active=None, seg=None, rec=None, ncol=1, Qr_term=None,
+                lin=None):
+        """lin = (model id, parameters [P] or [B, P]): A, Bm are isls_linearize's output for that model (isls_ff_args.lin_on)"""
         B, N, m, n = K.shape
         a = FfArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode, _pad=int(ncol) if ncol and ncol > 1 else 0)
+        if lin is not None:
+            if rec is None:
+                raise ValueError("lin goes with the packed records")
+            model, par = lin
+            if par.dtype != K.dtype or not par.is_contiguous() or par.ndim not in (1, 2) or (par.ndim == 2 and par.shape[0] != B):
+                raise ValueError("lin parameters: contiguous [P] or [B, P] of the pass's dtype")
+            a.lin_on, a.lin_model, a.lin_par, a.lin_par_sb = 1, int(model), _ptr(par), (par.shape[1] if par.ndim == 2 else 0)
         if Qr_term is not None:                                 # weight block of the last step (isls_ff_args.Qr_term): [n,n]
             if Qr is None or tuple(Qr.shape) not in ((n, n), (1, n, n), (1, 1, n, n)):
                 raise ValueError("Qr_term goes with a batch-shared, time-invariant Qr block")

@@ -141,6 +141,7 @@ class Engine:
         """Built-in forward model (ISLS_MODEL_*); par is [P] (shared) or [B,P] (per trajectory)."""
         self.model, self.model_par = int(model_id), self._t(par)
         self._outer_args = None
+        self._ab_made = None                                   # A, Bm no longer belong to the model in use
 
     def set_quadratic_cost(self, zs, Qs, seq, u_std):
         """Via-point quadratic cost (Base.set_quadratic_cost, isls/base.py:81-89); zs [nvia,n] or [B,nvia,n]."""
@@ -260,6 +261,40 @@ class Engine:
     def linearize(self):
         self.kern.linearize(self.model, self.model_par, self.xhat, self.uhat, self.A, self.Bm,
                             active=self.outer_active, stream=_stream_ptr())
+        self._mark_ab_made()
+
+    # ---- whose A, Bm the buffers hold: the feed-forward passes may use the model's structure only for the model's own
+    # linearisation (isls_ff_args.lin_on), never for a caller's A, B
+    def _mark_ab_made(self):
+        self._ab_made = (self.model, self.A.data_ptr(), self.Bm.data_ptr())
+
+    def ab_from_caller(self):
+        """A, Bm were written by somebody else (AB setter, get_AB callback): the dense records are the only valid form.
+        A cached isls_outer_args block keeps its pointers; run_outer() rewrites its hint fields when this state has changed."""
+        self._ab_made = None
+
+    def _apply_ff_lin(self, ff, rec):
+        """(re)write the hint fields of a marshalled isls_ff_args for the state of A, Bm now"""
+        lin = self.ff_lin(rec)
+        if lin is None:
+            ff.lin_on, ff.lin_model, ff.lin_par, ff.lin_par_sb = 0, 0, None, 0
+        else:
+            par = lin[1]
+            ff.lin_on, ff.lin_model, ff.lin_par = 1, int(lin[0]), par.data_ptr()
+            ff.lin_par_sb = par.shape[1] if par.ndim == 2 else 0
+        return lin
+
+    def ff_lin(self, rec):
+        """(model id, parameters) for isls_ff_args.lin_on, or None: the packed records are in use, A and Bm are what
+        isls_linearize wrote into the buffers the engine holds now, for the model set now, and the model is one whose
+        structure the record pass knows (ISLS_FF_LEAN=0 switches the form off)."""
+        if rec is None or not self.fast_dims or os.environ.get("ISLS_FF_LEAN", "1") == "0":
+            return None
+        if self.model not in (capi.MODEL_DI, capi.MODEL_ARM3R) or self.model_par is None:
+            return None
+        if getattr(self, "_ab_made", None) != (self.model, self.A.data_ptr(), self.Bm.data_ptr()):
+            return None
+        return (self.model, self.model_par)
 
     def _shared_hessian(self):
         """True when the cost Hessians are the same arrays for every trajectory of the batch: via-point cost with a batch-
@@ -326,7 +361,7 @@ class Engine:
         self.kern.riccati_ff(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                              Qr=Qr, Qr_term=Qr_term, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx,
                              zu=self.zu, lu=self.lu, solve_mode=self.solve_mode, active=active, seg=seg, rec=rec,
-                             stream=_stream_ptr())
+                             lin=self.ff_lin(rec), stream=_stream_ptr())
 
     def rollout(self, L, flags=0, cost_all=None, active=None):
         self.kern.rollout_ls(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
@@ -381,7 +416,8 @@ class Engine:
         Qr_ff, Qr_term = self._ff_weights(rec)
         ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                        Qr=Qr_ff, Qr_term=Qr_term, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
-                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=self.ff_seg(ff_nseg), rec=rec)
+                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=self.ff_seg(ff_nseg), rec=rec,
+                       lin=self.ff_lin(rec))
         ro = K.rollout_args(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
                             self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,
                             cost_new=self.cost_new, wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx, zu=self.zu,
@@ -393,6 +429,7 @@ class Engine:
                            iters=self.admm_iters, x_sets=self.x_sets, x_col0=self.x_col0, x_work=self.x_work,
                            u_sets=self.u_sets, u_col0=self.u_col0, u_work=self.u_work)
         self._outer_args = capi.OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=0, begin_done=int(bool(begin_done)))
+        self._outer_rec, self._outer_lin_state = rec, getattr(self, "_ab_made", None)
         self._advance_args = None
         self._outer_args.log = capi._ptr(log)
         self._outer_args.outer_active = capi._ptr(self.outer_active)
@@ -403,6 +440,10 @@ class Engine:
         """gain -> J x [ff -> rollout/line-search -> ADMM update] on the current stream (no host sync)."""
         fn = getattr(library(), f"isls_ilqr_admm_outer_{self.sfx}")
         fn.restype = ctypes.c_int
+        state = getattr(self, "_ab_made", None)
+        if state != getattr(self, "_outer_lin_state", ()):     # A, Bm changed hands since the block was marshalled / last run
+            self._apply_ff_lin(self._outer_args.ff, self._outer_rec)
+            self._outer_lin_state = state
         rc = fn(ctypes.byref(self._outer_args), ctypes.c_void_p(_stream_ptr()))
         if rc != capi.OK:
             raise capi.IslsError(f"isls_ilqr_admm_outer_{self.sfx} -> {rc}")
@@ -445,6 +486,8 @@ class Engine:
             self._advance_args = (key, K.advance_args(acc, lin, exp, admm_active=self.admm_active, iters=self.admm_iters,
                                                       lx=self.lx, lu=self.lu, res_prev=self.res_prev))
         self.kern.outer_advance(self._advance_args[1], self.sfx, stream=_stream_ptr())
+        if linearize:
+            self._mark_ab_made()                               # the launch linearised the trajectories still iterating
 
     def reduce(self, table=None, rank=0):
         """[sum cost, max prim, max dual, #active, #failed] of the local shard, left on the device: in `out5`, or straight

@@ -109,6 +109,7 @@ class iSLS(Base):
             else:
                 setattr(e, name, new)
                 e._outer_args = None
+        e.ab_from_caller()
         self._user_AB = True
 
     @property

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ISLS_VERSION 105   /* 105: isls_outer_advance_*, isls_outer_args.begin_done; 104: isls_riccati_gain_ff_*; 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
+#define ISLS_VERSION 106   /* 106: isls_ff_args.lin_on (model-structured feed-forward pass); 105: isls_outer_advance_*, isls_outer_args.begin_done; 104: isls_riccati_gain_ff_*; 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
 
 #define ISLS_OK 0
 #define ISLS_ERR_ARG (-1)
@@ -186,6 +186,17 @@ typedef struct isls_ff_args {
                                      * constraint: notebooks/3DoF robot/State and control bound constraints.ipynb cell 22) is
                                      * then passed with a zero time stride and keeps the one-hand-off record kernel.  Record
                                      * path with time-invariant Qr / Rr only (else ISLS_ERR_UNSUPPORTED: pass the full [N,n,n]) */
+    int32_t lin_on;                 /* != 0 (record path only): A and Bm are what isls_linearize_* wrote for `lin_model`, so the pass may
+                                     * read only the [K | fac (| J)] tail of every record (27 of 81 words at n=6, m=3; 42 of 150 at n=9) and
+                                     * evaluate (A + B K)'v = A'v + K'(B'v) from the model's structure: ISLS_MODEL_DI (A = [I aI; 0 I],
+                                     * B = [b0 I; b1 I]) or ISLS_MODEL_ARM3R (A = [I dtI 0; 0 I 0; J dtJ 0], B = [hI; dtI; hJ], the six
+                                     * words of J = A[6:8,0:3] the gain pass keeps behind fac in the records of the pair (9,3)).  A hint: the records stay complete and the dense form runs where the
+                                     * structured one does not apply (time-varying Qr / Rr); another model is ISLS_ERR_UNSUPPORTED.
+                                     * The same products in another association: results equal up to rounding.  The caller must NOT set
+                                     * it for A, Bm of its own (get_AB callbacks) */
+    int32_t lin_model;
+    const void *lin_par;            /* isls_linearize_args.model_par of that model */
+    int64_t lin_par_sb;             /* batch stride of lin_par in words (0: shared) */
 } isls_ff_args;
 
 int isls_riccati_ff_f64(const isls_ff_args *a, void *stream);

@@ -7,7 +7,8 @@ from isls import _capi as capi
 
 
 class DualKernels:
-    def __init__(self, oracle, hip, tol=1e-10, int_exact=True, verbose=False, ff_nseg=1, ff_record=False, ti_weights=False):
+    def __init__(self, oracle, hip, tol=1e-10, int_exact=True, verbose=False, ff_nseg=1, ff_record=False, ti_weights=False,
+                 ff_lin=False):
         self.oracle, self.hip, self.tol, self.int_exact, self.verbose = oracle, hip, tol, int_exact, verbose
         # True: ADMM weights that are the same at every step ([N,d,d] / [N,d] tiles of one block, what compute_Rr_Qr builds from
         # a scalar rho) reach the HIP side as ONE block ([1,d,d] / [1,d]: time stride 0), the way isls.Engine hands them over --
@@ -20,6 +21,10 @@ class DualKernels:
         # True: the HIP gain pass also writes the packed step records (isls_gain_args.rec, NaN-filled before) and the HIP
         # feed-forward passes read those instead of A, B, K, Quu, fac, Qux; the oracle keeps the reference's recursion
         self.ff_record, self._rec = ff_record, None
+        # True: the HIP record passes get the hint isls.Engine gives them (isls_ff_args.lin_on) when A, B came from `linearize`
+        # of a double integrator or the 3R arm: [K | fac] of the records + the model's structure instead of the dense
+        # [Phi | B] blocks; `lin_calls` counts the passes that ran with it
+        self.ff_lin, self._lin, self.lin_calls = ff_lin, None, 0
         self.max_err = {}
         self.calls = 0
 
@@ -67,6 +72,11 @@ class DualKernels:
             dkw = dict(dkw, rec=self._rec)
         if self.ff_record and name == "riccati_ff" and self._rec is not None and self._rec_dims == tuple(dargs[4].shape[:2]):
             dkw = dict(dkw, rec=self._rec)
+            if self.ff_lin and self._lin is not None:
+                dkw = dict(dkw, lin=self._lin)
+                self.lin_calls += 1
+        if name == "linearize":                                # what the engine knows about its A, B (Engine.ff_lin)
+            self._lin = self._lin_hint(args[0], args[1], dargs[1])
         for blk in ("x", "u"):                                 # set descriptors hold pointers: rebuild them on the device
             if dkw.get(blk + "_sets") is not None:
                 dkw[blk + "_sets"] = self._rebuild_sets(dkw[blk + "_sets"]._spec, dkw[blk + "_work"])
@@ -79,6 +89,22 @@ class DualKernels:
         for k in kw:
             if isinstance(kw[k], np.ndarray):
                 self._compare(name, k, kw[k], dkw[k])
+
+    @staticmethod
+    def _lin_hint(model, par, par_dev):
+        from isls import models
+        if model == capi.MODEL_ARM3R:
+            return (capi.MODEL_ARM3R, par_dev)
+        if model == capi.MODEL_DI:
+            return (capi.MODEL_DI, par_dev)
+        if model == capi.MODEL_LTI:                            # isls.models.LTI recognises a double integrator in a dense pair
+            p = np.asarray(par, dtype=np.float64)
+            for n in range(2, 17, 2):                          # par = [A (n x n), B (n x n/2)]
+                if p.size == n * n + n * (n // 2):
+                    mdl = models.LTI(p[:n * n].reshape(n, n), p[n * n:].reshape(n, n // 2))
+                    if mdl.model_id == capi.MODEL_DI:
+                        return (capi.MODEL_DI, torch.as_tensor(np.asarray(mdl.params(), dtype=par.dtype)).cuda())
+        return None
 
     def _rebuild_sets(self, spec, work):
         """The same descriptor (and its further stages) over device copies of the operands."""

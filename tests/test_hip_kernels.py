@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def dual(oracle):
     from dual import DualKernels, hip_kernels
-    return lambda tol=1e-10, ff_nseg=1, ff_record=False, ti_weights=False: DualKernels(
-        oracle, hip_kernels(), tol=tol, ff_nseg=ff_nseg, ff_record=ff_record, ti_weights=ti_weights)
+    return lambda tol=1e-10, ff_nseg=1, ff_record=False, ti_weights=False, ff_lin=False: DualKernels(
+        oracle, hip_kernels(), tol=tol, ff_nseg=ff_nseg, ff_record=ff_record, ti_weights=ti_weights, ff_lin=ff_lin)
 
 
 def _report(dk):
@@ -264,6 +264,57 @@ def test_one_handoff_feedforward_on_time_invariant_weights(dual, which, ff_nseg,
     d = OracleDriver(dk, pa, dtype=f, **kw)
     d.run(2, 20, 4, 0.0)
     assert dk._rec is not None
+    _report(dk)
+
+
+def _di_config(dim, batch, N, seed):
+    """config2's problem for a double integrator of another dimension (n = 2 dim, m = dim)"""
+    rng = np.random.default_rng(seed)
+    n, m, dt = 2 * dim, dim, 0.01
+    A, B = P.double_integrator_AB(dim, 2, dt)
+    x0, target = np.zeros((batch, n)), np.zeros((batch, n))
+    x0[:, :dim] = rng.uniform(-0.5, 0.5, size=(batch, dim))
+    target[:, :dim] = rng.uniform(0.5, 1.5, size=(batch, dim))
+    zs = np.zeros((batch, 2, n))
+    zs[:, 1] = target
+    seq = np.zeros(N, dtype=np.int32)
+    seq[N - 1] = 1
+    return dict(name=f"di{dim}d", n=n, m=m, N=N, dt=dt, A=A, B=B, zs=zs, Qs=np.stack([np.zeros((n, n)), 1e3 * np.eye(n)]), seq=seq,
+                u_std=1e-3, x0=x0, u0=np.zeros((batch, N, m)), u_lo=-3.0, u_hi=3.0, rho_u=1e-2, relax=1.0, model=P.MODEL_LTI)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 1e-4)])
+@pytest.mark.parametrize("ff_nseg", [1, 3])
+@pytest.mark.parametrize("which", ["di1d", "di2d", "di3d_u", "di3d_xu", "arm"])
+def test_model_structured_feedforward(dual, golden, which, ff_nseg, dtype, tol):
+    """isls_ff_args.lin_on: the record pass reads only [K | fac] of every record and evaluates (A + B K)'v = A'v + K'(B'v) from the
+    structure of the model whose linearisation A, B are -- double integrators of dimension 1, 2, 3 (ISLS_MODEL_DI) and the planar
+    arm (ISLS_MODEL_ARM3R, J from A) -- against the oracle's four-term recursion on the dense arrays, whole ADMM traces kernel
+    call by kernel call, sequential and time-parallel, batch sizes that leave wavefront slots empty, both precisions (the arm in
+    fp64 and fp32 at its conditioning-aware bounds, as in the dense-form tests)."""
+    f = np.float64 if dtype == "f64" else np.float32
+    if which == "arm":
+        g = golden("g4_arm3r.npz")
+        cfg = P.config3(batch=8, N=100, seed=0)
+        amp = max(float(v) for v in g["o2_sens"]) / 1e-15
+        tol = max(1e-10, 10 * float(np.max(g["o2_sens"]))) if dtype == "f64" else max(1e-4, 10 * amp * 2.0 ** -24)
+        pa, kw = problem_arrays(cfg, range(7), dtype=f), dict(rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+        steps = (2, cfg["max_line_search"], 4)
+    else:
+        dim = {"di1d": 1, "di2d": 2}.get(which, 3)
+        cfg = _di_config(dim, batch=40, N=100, seed=5)
+        nb = {1: 23, 2: 13, 3: 11}[dim]                            # 21 / 10 / 7 trajectories per wavefront: a partly filled last one
+        pa, kw = problem_arrays(cfg, range(nb), dtype=f), dict(rho_u=cfg["rho_u"], relax=cfg["relax"])
+        if which == "di3d_xu":
+            pa["x_lo"] = np.full((100, 6), -np.inf, dtype=f); pa["x_hi"] = np.full((100, 6), np.inf, dtype=f)
+            pa["x_lo"][:, 3:6], pa["x_hi"][:, 3:6] = -1.2, 1.2
+            kw = dict(rho_x=0.05, rho_u=cfg["rho_u"], project_x=True, relax=1.5)
+        steps = (2, 20, 4)
+    dk = dual(tol=tol, ff_nseg=ff_nseg, ff_record=True, ti_weights=True, ff_lin=True)
+    dk.int_exact = dtype == "f64" and which != "arm"               # near-ties of the arg-min may flip in fp32 / on the arm
+    d = OracleDriver(dk, pa, dtype=f, **kw)
+    d.run(*steps, 0.0)
+    assert dk._rec is not None and dk.lin_calls >= steps[0] * steps[2]   # the structured form really ran
     _report(dk)
 
 
