@@ -43,6 +43,8 @@ struct GainP {
     const T *xhat, *uhat, *zx, *lx, *zu, *lu;
     T *kff;
     int rev;                       // 1: the grid walks the trajectory blocks from the last to the first
+    const T *lin_par;              // LIN form (isls_gain_args.lin_on): the model's parameters, batch stride lin_par_sb
+    int64_t lin_par_sb;
 };
 
 // 1/sqrt(a) by v_rsq + two coupled Newton steps (g -> sqrt(a), h -> 1/(2 sqrt(a))): 9 instructions against the ~30 of
@@ -105,9 +107,17 @@ __device__ __forceinline__ bool chol_upper_rd(const T (&A)[M][M], T (&U)[M][M], 
 #ifndef ISLS_GAIN_OCC
 #define ISLS_GAIN_OCC 1
 #endif
-template <typename T, int NX, int NU, int D, int MODE, bool FF, bool REC, bool ARR>
+// LIN = 1 (isls_gain_args.lin_on, ISLS_MODEL_DI): [A B] = [I aI b0 I; 0 I b1 I] is not loaded or staged at all.  Column i of it
+// has at most two entries, c1 at row r1 and c2 at row r2 > r1, so  row i of [A B]'V = c1 V[r1,:] + c2 V[r2,:]  (two rows of V
+// instead of all n: 12 of 36 multiply-adds and LDS words at n = 6),  M = S [A B]  takes one or two products per entry (12 of
+// 54, none of the 54 words of [A B]),  and  Phi[:, i] = A[:, i] + B K[:, i]  one product per entry (6 of 18).  Every term of the
+// dense form that is left out adds an exact zero, and the ones that stay are written in the dense form's order and source
+// form.  fp64: bit-identical to the dense kernel (finite operands; tests compare K, records and k bit by bit).  fp32: equal to
+// rounding only -- there the compiler packs some two-term sums of the DENSE kernel into unfused v_pk_mul / v_pk_add pairs.
+template <typename T, int NX, int NU, int D, int MODE, bool FF, bool REC, bool ARR, int LIN = 0>
 __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T> p)
 {
+    static_assert(LIN == 0 || NX == 2 * NU, "double integrator: n = 2 d, m = d");
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
     constexpr int V_OFF = 0, AB_OFF = V_OFF + NX * NX, Q_OFF = AB_OFF + NX * W, K_OFF = Q_OFF + NU * W;
     constexpr int DUMP_OFF = K_OFF + NU * NX;              // W words that absorb the LDS writes of lanes with nothing to publish
@@ -174,6 +184,20 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
     const int64_t a_st = p.A.st, b_st = p.Bm.st;
     const T zmask = (xl || has_cux) ? T(1) : T(0);            // Cux absent -> 0
     const T xmask = xl ? T(1) : T(0);
+    // LIN form: the lane's column of [A B] (see the kernel's head)
+    T l_a = T(0), l_b0 = T(0), l_b1 = T(0), l_c1 = T(0), l_c2 = T(0), colc[NX];
+    int l_r1 = 0, l_r2 = 0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) colc[k] = T(0);
+    if constexpr (LIN == 1) {
+        const T *lp = p.lin_par + (int64_t)bb * p.lin_par_sb;
+        l_a = lp[0]; l_b0 = lp[1]; l_b1 = lp[2];
+        if (xl && i < NU) { l_c1 = T(1); l_r1 = i; l_c2 = T(0); l_r2 = i; }
+        else if (xl) { l_c1 = l_a; l_r1 = i - NU; l_c2 = T(1); l_r2 = i; }
+        else { l_c1 = l_b0; l_r1 = a_row; l_c2 = l_b1; l_r2 = NU + a_row; }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) colc[k] = (k == l_r1) ? l_c1 : ((k == l_r2) ? l_c2 : T(0));
+    }
 
     // ---- FF form: per-lane plan of the linear terms (lane i owns c_i, d_i = xhat_i - (z_i - lambda_i), v_i) ----------
     const bool ff_hasreg = FF && (xl ? p.Qr.p != nullptr : p.Rr.p != nullptr);
@@ -265,10 +289,12 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
     auto fetch = [&](int tq, Stage &g) {
         const int t = __builtin_amdgcn_readfirstlane(tq);      // uniform: the offsets below are scalar arithmetic
         const int64_t oa = (int64_t)t * a_st, ob = (int64_t)t * b_st;
+        if constexpr (LIN == 0) {
 #pragma unroll
-        for (int j = 0; j < JA; ++j) g.ra[j] = ISLS_NT_GAIN_LD ? ld_stream(pA[j] + oa) : pA[j][oa];
+            for (int j = 0; j < JA; ++j) g.ra[j] = ISLS_NT_GAIN_LD ? ld_stream(pA[j] + oa) : pA[j][oa];
 #pragma unroll
-        for (int j = 0; j < JB; ++j) g.rb[j] = ISLS_NT_GAIN_LD ? ld_stream(pB[j] + ob) : pB[j][ob];
+            for (int j = 0; j < JB; ++j) g.rb[j] = ISLS_NT_GAIN_LD ? ld_stream(pB[j] + ob) : pB[j][ob];
+        }
         const T *cl = pcl + (int64_t)t * cl_st, *cr = pcr + (int64_t)t * cr_st;
 #pragma unroll
         for (int j = 0; j < NX; ++j) g.crow[j] = cl[j];
@@ -358,10 +384,12 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
         constexpr bool flush_prev = decltype(FLUSH)::value;
         T *imq = img + q * IMG;
         // stage [A_t B_t] into the record: row k = [A[k,:] B[k,:]]
+        if constexpr (LIN == 0) {
 #pragma unroll
-        for (int j = 0; j < JA; ++j) rec[dA[j]] = g.ra[j];
+            for (int j = 0; j < JA; ++j) rec[dA[j]] = g.ra[j];
 #pragma unroll
-        for (int j = 0; j < JB; ++j) rec[dB[j]] = g.rb[j];
+            for (int j = 0; j < JB; ++j) rec[dB[j]] = g.rb[j];
+        }
         T ff_c0v = T(0);
         if constexpr (FF) {
             rec[ff_ddst] = ff_dmask * (ff_hmask * g.hv - (g.zv - g.lv));
@@ -385,6 +413,27 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
         constexpr int AHEAD_ = (NX * NX + NX * W <= 100) ? (FF ? ISLS_GAIN_AHEAD_FF : ISLS_GAIN_AHEAD) : 2;
         constexpr int AHEAD = AHEAD_ < NX ? AHEAD_ : NX;
         T S[NX], colv[NX], Vr[NX][NX], Fr[NX][W];
+        T ff_v[NX], ff_dr[NX];
+        if constexpr (LIN == 1) {
+            // (1) S = c1 V[r1,:] + c2 V[r2,:]: the dense sum's two non-zero terms in its order (r1 < r2, or one term and + 0),
+            // written the way the dense loop writes them (fp64: fused multiply-adds in both kernels)
+            T v1[NX], v2[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) { v1[j] = Vs[l_r1 * NX + j]; v2[j] = Vs[l_r2 * NX + j]; colv[j] = colc[j]; }
+            if constexpr (FF) {
+#pragma unroll
+                for (int k = 0; k < NX; ++k) { ff_v[k] = rec[VV_OFF + k]; ff_dr[k] = rec[ff_doff + k]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<NX>([&](auto KK) {
+                constexpr int k = decltype(KK)::value;
+                T acc = T(0);
+                acc += l_c1 * v1[k];
+                acc += l_c2 * v2[k];
+                S[k] = acc;
+                if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, k>{});
+            });
+        } else {
 #pragma unroll
         for (int k = 0; k < NX; ++k) colv[k] = ABs[k * W + i];
 #pragma unroll
@@ -392,7 +441,6 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
 #pragma unroll
             for (int j = 0; j < NX; ++j) Vr[k][j] = Vs[k * NX + j];
         }
-        T ff_v[NX], ff_dr[NX];
         if constexpr (FF) {
 #pragma unroll
             for (int k = 0; k < NX; ++k) { ff_v[k] = rec[VV_OFF + k]; ff_dr[k] = rec[ff_doff + k]; }
@@ -417,6 +465,7 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, k>{});
         });
+        }
         // FF form: c_i, and the u-lanes' qu_r = cu_r + (B'v)_r from their column of B
         T ff_ci = T(0);
         if constexpr (FF) {
@@ -432,6 +481,25 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
         }
         // (2) M = C_row + S [A B]      (Qxx = Cxx + (A'V)A etc., isls.py:288-290)
         T M[W];
+        if constexpr (LIN == 1) {
+            // column c of [A B]: c < d: e_c;  d <= c < n: a e_{c-d} + e_c;  n + r: b0 e_r + b1 e_{d+r}
+            static_for<NX>([&](auto KK) {
+                constexpr int k = decltype(KK)::value;
+                if constexpr (k < NU) {
+                    M[k] = S[k];
+                    T acc = T(0);
+                    acc += S[k] * l_b0;
+                    acc += S[NU + k] * l_b1;
+                    M[NX + k] = acc;
+                } else {
+                    // the dense sum rounds a S[k-d] and then adds S[k] (times an exact one): never one fused operation
+#pragma clang fp contract(off)
+                    const T t_a = S[k - NU] * l_a;
+                    M[k] = t_a + S[k];
+                }
+                if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, NX + k>{});
+            });
+        } else {
 #pragma unroll
         for (int c = 0; c < W; ++c) M[c] = T(0);
         static_for<NX>([&](auto KK) {
@@ -445,6 +513,7 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
             }
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, NX + k>{});
         });
+        }
 #pragma unroll
         for (int c = 0; c < W; ++c) M[c] = (c < NX) ? fma(g.crow[c], zmask, M[c]) : g.crow[c] + M[c];   // one rounding either way
         __builtin_amdgcn_sched_barrier(0);
@@ -495,7 +564,7 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
         // no faster with the feed-forward pass inside (208-213 us both) and 6 us slower without (172 vs 166 us); capping the
         // kernel at 256 registers -- -DISLS_GAIN_OCC=2 -- spills 456 B into scratch and takes 385 us: its real pressure is ~370)
         T Bq[NX][NU];
-        if constexpr (ISLS_GAIN_REREAD_B) {
+        if constexpr (ISLS_GAIN_REREAD_B && LIN == 0) {
 #pragma unroll
             for (int k = 0; k < NX; ++k)
 #pragma unroll
@@ -505,8 +574,12 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
         static_for<NX>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
             T ph = colv[k];
+            if constexpr (LIN == 1) {
+                ph += (k < NU ? l_b0 : l_b1) * Kc[k % NU];        // row k of B has one entry
+            } else {
 #pragma unroll
-            for (int r = 0; r < NU; ++r) ph += (ISLS_GAIN_REREAD_B ? Bq[k][r] : Fr[k][NX + r]) * Kc[r];
+                for (int r = 0; r < NU; ++r) ph += (ISLS_GAIN_REREAD_B ? Bq[k][r] : Fr[k][NX + r]) * Kc[r];
+            }
             phc[k] = ph;
             if constexpr (flush_prev) send_at(t + 1, std::integral_constant<int, 2 * NX + k>{});
         });
@@ -703,6 +776,15 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     p.xhat = p.uhat = p.zx = p.lx = p.zu = p.lu = nullptr; p.kff = nullptr;
     static const int rev_mode = [] { const char *e = getenv("ISLS_GAIN_REV"); return e ? atoi(e) : 0; }();   // EXPERIMENT
     p.rev = rev_mode ? 1 : 0;
+    // model-structured form (isls_gain_args.lin_on): the double integrator, on the record forms the drivers use; a hint -- A
+    // and Bm are complete, so any other case runs the dense kernel (ISLS_GAIN_LEAN=0 switches the form off)
+    static const bool lean_env = [] { const char *e = getenv("ISLS_GAIN_LEAN"); return !e || atoi(e) != 0; }();
+    bool lin_di = false;
+    if (a.lin_on) {
+        if (a.lin_model == ISLS_MODEL_DI) { if (a.n != 2 * a.m || !a.lin_par) return ISLS_ERR_ARG; lin_di = lean_env && a.rec && !a.Qux; }
+        else if (a.lin_model != ISLS_MODEL_ARM3R) return ISLS_ERR_UNSUPPORTED;      // the arm's records carry J; its gain pass is the dense one
+    }
+    p.lin_par = (const T *)a.lin_par; p.lin_par_sb = a.lin_par_sb;
     // the first feed-forward pass rides along when it would run on this pass's records with time-invariant Qr / Rr rows
     const bool with_ff = ff && gain_ff_dims(a.n, a.m) && a.rec && ff->rec == a.rec && ff->k && ff->B == a.B && ff->N == a.N && ff->n == a.n && ff->m == a.m &&
                          ff->solve_mode == a.solve_mode && ff->active == a.active && ff->c0x.p && ff->c0u.p &&
@@ -717,11 +799,19 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     }
 #define LAUNCH_G(NX_, NU_, MODE_, FF_, REC_, ARR_) \
     hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_, REC_, ARR_>), dim3(grid), dim3(64), 0, s, p)
+#define LAUNCH_GL(NX_, NU_, MODE_, FF_) \
+    hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_, true, false, 1>), dim3(grid), dim3(64), 0, s, p)
 #define LAUNCH_M(NX_, NU_, MODE_)                                                           \
     {                                                                                       \
         if (with_ff) {                                                                      \
-            if constexpr (gain_ff_dims(NX_, NU_)) LAUNCH_G(NX_, NU_, MODE_, true, true, false); \
-        } else if (a.rec && !a.Qux) LAUNCH_G(NX_, NU_, MODE_, false, true, false);          \
+            if constexpr (gain_ff_dims(NX_, NU_)) {                                         \
+                if constexpr (NX_ == 2 * NU_) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, true); else LAUNCH_G(NX_, NU_, MODE_, true, true, false); } \
+                else LAUNCH_G(NX_, NU_, MODE_, true, true, false);                          \
+            }                                                                               \
+        } else if (a.rec && !a.Qux) {                                                       \
+            if constexpr (NX_ == 2 * NU_) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, false); else LAUNCH_G(NX_, NU_, MODE_, false, true, false); } \
+            else LAUNCH_G(NX_, NU_, MODE_, false, true, false);                             \
+        }                                                                                   \
         else if (a.rec) LAUNCH_G(NX_, NU_, MODE_, false, true, true);                       \
         else LAUNCH_G(NX_, NU_, MODE_, false, false, true);                                 \
     }
@@ -735,6 +825,7 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
 #undef LAUNCH_M
+#undef LAUNCH_GL
 #undef LAUNCH_G
     if (did_ff) *did_ff = with_ff;
     return check_launch();

@@ -17,7 +17,7 @@ try:  # torch is plumbing (device memory, streams); the binding itself works on 
 except Exception:  # pragma: no cover
     torch = None
 
-ABI_VERSION = 106            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
+ABI_VERSION = 107            # ISLS_VERSION of include/isls_hip.h these ctypes structs mirror
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ST_NOT_PD, ST_NAN_COST, ST_LS_REJECT = 1, 2, 4
 SOLVE_CHOL, SOLVE_INV = 0, 1
@@ -39,7 +39,8 @@ class GainArgs(C.Structure):
                 ("solve_mode", C.c_int32), ("_pad", C.c_int32),
                 ("A", View), ("Bm", View), ("Cxx", View), ("Cuu", View), ("Cux", View),
                 ("K", C.c_void_p), ("Quu", C.c_void_p), ("fac", C.c_void_p), ("Qux", C.c_void_p),
-                ("status", C.c_void_p), ("active", C.c_void_p), ("rec", C.c_void_p)]
+                ("status", C.c_void_p), ("active", C.c_void_p), ("rec", C.c_void_p),
+                ("lin_on", C.c_int32), ("lin_model", C.c_int32), ("lin_par", C.c_void_p), ("lin_par_sb", C.c_int64)]
 
 
 class FfSeg(C.Structure):
@@ -371,9 +372,22 @@ class Kernels:
 
     # -- argument builders (also used to fill OuterArgs) --------------------------------------------
     @staticmethod
-    def gain_args(A, Bm, Cxx, Cuu, K, Quu, fac, Qux, Cux=None, solve_mode=SOLVE_CHOL, status=None, active=None, rec=None):
+    def _set_lin(a, lin, B, dtype):
+        """hint fields of isls_gain_args / isls_ff_args: lin = (model id, parameters [P] or [B, P]) or None"""
+        if lin is None:
+            a.lin_on, a.lin_model, a.lin_par, a.lin_par_sb = 0, 0, None, 0
+            return
+        model, par = lin
+        if par.dtype != dtype or not par.is_contiguous() or par.ndim not in (1, 2) or (par.ndim == 2 and par.shape[0] != B):
+            raise ValueError("lin parameters: contiguous [P] or [B, P] of the pass's dtype")
+        a.lin_on, a.lin_model, a.lin_par, a.lin_par_sb = 1, int(model), _ptr(par), (par.shape[1] if par.ndim == 2 else 0)
+
+    @staticmethod
+    def gain_args(A, Bm, Cxx, Cuu, K, Quu, fac, Qux, Cux=None, solve_mode=SOLVE_CHOL, status=None, active=None, rec=None, lin=None):
+        """lin = (model id, parameters): A, Bm are isls_linearize's output for that model (isls_gain_args.lin_on)"""
         B, N, m, n = K.shape
         a = GainArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode)
+        Kernels._set_lin(a, lin, B, K.dtype)
         a.A, a.Bm = make_view(A, B, N, (n, n), "A"), make_view(Bm, B, N, (n, m), "B")
         a.Cxx, a.Cuu = make_view(Cxx, B, N, (n, n), "Cxx"), make_view(Cuu, B, N, (m, m), "Cuu")
         a.Cux = make_view(Cux, B, N, (m, n), "Cux")
@@ -390,13 +404,9 @@ class Kernels:
         """lin = (model id, parameters [P] or [B, P]): A, Bm are isls_linearize's output for that model (isls_ff_args.lin_on)"""
         B, N, m, n = K.shape
         a = FfArgs(B=B, N=N, n=n, m=m, solve_mode=solve_mode, _pad=int(ncol) if ncol and ncol > 1 else 0)
-        if lin is not None:
-            if rec is None:
-                raise ValueError("lin goes with the packed records")
-            model, par = lin
-            if par.dtype != K.dtype or not par.is_contiguous() or par.ndim not in (1, 2) or (par.ndim == 2 and par.shape[0] != B):
-                raise ValueError("lin parameters: contiguous [P] or [B, P] of the pass's dtype")
-            a.lin_on, a.lin_model, a.lin_par, a.lin_par_sb = 1, int(model), _ptr(par), (par.shape[1] if par.ndim == 2 else 0)
+        if lin is not None and rec is None:
+            raise ValueError("lin goes with the packed records")
+        Kernels._set_lin(a, lin, B, K.dtype)
         if Qr_term is not None:                                 # weight block of the last step (isls_ff_args.Qr_term): [n,n]
             if Qr is None or tuple(Qr.shape) not in ((n, n), (1, n, n), (1, 1, n, n)):
                 raise ValueError("Qr_term goes with a batch-shared, time-invariant Qr block")

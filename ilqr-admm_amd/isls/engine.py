@@ -273,15 +273,11 @@ class Engine:
         A cached isls_outer_args block keeps its pointers; run_outer() rewrites its hint fields when this state has changed."""
         self._ab_made = None
 
-    def _apply_ff_lin(self, ff, rec):
-        """(re)write the hint fields of a marshalled isls_ff_args for the state of A, Bm now"""
+    def _apply_ff_lin(self, blocks, rec):
+        """(re)write the hint fields of marshalled isls_gain_args / isls_ff_args blocks for the state of A, Bm now"""
         lin = self.ff_lin(rec)
-        if lin is None:
-            ff.lin_on, ff.lin_model, ff.lin_par, ff.lin_par_sb = 0, 0, None, 0
-        else:
-            par = lin[1]
-            ff.lin_on, ff.lin_model, ff.lin_par = 1, int(lin[0]), par.data_ptr()
-            ff.lin_par_sb = par.shape[1] if par.ndim == 2 else 0
+        for a in blocks:
+            capi.Kernels._set_lin(a, lin, self.B, self.dtype)
         return lin
 
     def ff_lin(self, rec):
@@ -347,7 +343,7 @@ class Engine:
         self.kern.riccati_gain(self.A, self.Bm, *self.hessians(), self.K, self.Quu if full else None,
                                self.fac if full else None, self.Qux if full else None,
                                Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active, rec=rec,
-                               stream=_stream_ptr())
+                               lin=self.ff_lin(rec), stream=_stream_ptr())
 
     def _ff_weights(self, rec):
         """(Qr, Qr_term) operands of a feed-forward pass: the terminal-block form on the packed records when it applies"""
@@ -412,7 +408,7 @@ class Engine:
         full = rec is None
         gain = K.gain_args(self.A, self.Bm, *self.hessians(), self.K, self.Quu if full else None, self.fac if full else None,
                            self.Qux if full else None, Cux=self.Cux, solve_mode=self.solve_mode, status=self.status,
-                           active=self.admm_active, rec=rec)
+                           active=self.admm_active, rec=rec, lin=self.ff_lin(rec))
         Qr_ff, Qr_term = self._ff_weights(rec)
         ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                        Qr=Qr_ff, Qr_term=Qr_term, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
@@ -442,7 +438,7 @@ class Engine:
         fn.restype = ctypes.c_int
         state = getattr(self, "_ab_made", None)
         if state != getattr(self, "_outer_lin_state", ()):     # A, Bm changed hands since the block was marshalled / last run
-            self._apply_ff_lin(self._outer_args.ff, self._outer_rec)
+            self._apply_ff_lin((self._outer_args.gain, self._outer_args.ff), self._outer_rec)
             self._outer_lin_state = state
         rc = fn(ctypes.byref(self._outer_args), ctypes.c_void_p(_stream_ptr()))
         if rc != capi.OK:

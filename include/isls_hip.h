@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ISLS_VERSION 106   /* 106: isls_ff_args.lin_on (model-structured feed-forward pass); 105: isls_outer_advance_*, isls_outer_args.begin_done; 104: isls_riccati_gain_ff_*; 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
+#define ISLS_VERSION 107   /* 107: isls_gain_args.lin_on; 106: isls_ff_args.lin_on (model-structured feed-forward pass); 105: isls_outer_advance_*, isls_outer_args.begin_done; 104: isls_riccati_gain_ff_*; 103: project_rows: Dykstra / project_soc algorithms, shell + multilinear sets, row masks; 102: timing context, reduce table */
 
 #define ISLS_OK 0
 #define ISLS_ERR_ARG (-1)
@@ -119,6 +119,14 @@ typedef struct isls_gain_args {
                             * steps t = N-1 are not written.  Scratch semantics: the places of trajectories that are
                             * inactive (or past the batch in the last wavefront) are overwritten too, with a copy of
                             * another trajectory's record -- a consumer must use the same `active` mask as this pass   */
+    int32_t lin_on;        /* != 0: A and Bm are what isls_linearize_* wrote for `lin_model` (same contract as isls_ff_args.lin_on).
+                            * ISLS_MODEL_DI: the pass (record forms without Quu / fac / Qux arrays) neither loads nor stages A, Bm
+                            * and evaluates [A B]'V [A B] and A + B K from the two non-zero entries of every column -- the same
+                            * sums in the same order: fp64 results bit-identical to the dense pass, fp32 equal to rounding.  ISLS_MODEL_ARM3R: accepted,
+                            * dense pass.  A hint: every other case runs the dense pass */
+    int32_t lin_model;
+    const void *lin_par;   /* isls_linearize_args.model_par of that model */
+    int64_t lin_par_sb;    /* its batch stride in words (0: shared) */
 } isls_gain_args;
 
 /* elements of the packed-record buffer (see isls_gain_args.rec) */

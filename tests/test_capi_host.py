@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(capi.EXPORTED) == names                      # the binding knows exactly the header's surface
     lib.isls_version.restype = ctypes.c_int
-    assert lib.isls_version() == capi.ABI_VERSION == 106
+    assert lib.isls_version() == capi.ABI_VERSION == 107
     assert b"unsupported" in lib.isls_error_string(capi.ERR_UNSUPPORTED)
 
 

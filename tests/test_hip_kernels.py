@@ -647,6 +647,84 @@ def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x, dtype, to
     assert err < tol, f"second pass k: rel err {err:.3e}"
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("mode", [capi.SOLVE_CHOL, capi.SOLVE_INV])
+@pytest.mark.parametrize("dim,batch", [(1, 23), (2, 13), (3, 11)])
+def test_structured_gain_pass_is_bit_identical(dim, batch, mode, dtype):
+    """isls_gain_args.lin_on (ISLS_MODEL_DI): the gain pass that neither loads nor stages [A B] and takes [A B]'V [A B] and
+    A + B K from the two non-zero entries per column against the dense pass -- K, every written word of the packed records,
+    and (entry point isls_riccati_gain_ff_*) the first k -- for double integrators of dimension 1, 2, 3, both solve modes, a
+    partly filled last wavefront and an inactive trajectory.  fp64: the SAME bits (the terms left out add exact zeros, the
+    others keep the dense order).  fp32: equal to rounding only -- the compiler packs some two-term sums of the dense fp32
+    kernel into unfused v_pk_mul / v_pk_add pairs and fuses them in the structured one (which reproduces a numpy emulation of
+    the fused sequence bit for bit; the dense kernel is the one a unit in the last place off): 1e-5 relative, observed 3e-7 to
+    1e-6 after 56 steps.  The dense pass itself is checked against the oracle elsewhere; here the contract of the hint is."""
+    import torch
+    from dual import hip_kernels
+    from isls import models
+    hk = hip_kernels()
+    f = np.float64 if dtype == "f64" else np.float32
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    rng = np.random.default_rng(11 + dim)
+    N, n, m, B = 57, 2 * dim, dim, batch
+    A1, B1 = P.double_integrator_AB(dim, 2, 0.01)
+    mdl = models.LTI(A1, B1)
+    assert mdl.model_id == capi.MODEL_DI
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    rn = lambda *shape: rng.standard_normal(shape).astype(f)   # noqa: E731
+    par = dev(np.asarray(mdl.params(), dtype=f))
+    xhat, uhat = dev(rn(B, N, n)), dev(0.3 * rn(B, N, m))
+    A, Bm = torch.zeros(B, N, n, n, dtype=tdt, device="cuda"), torch.zeros(B, N, n, m, dtype=tdt, device="cuda")
+    hk.linearize(capi.MODEL_DI, par, xhat, uhat, A, Bm)
+    assert np.array_equal(A[3, 7].cpu().numpy(), A1.astype(f)) and np.array_equal(Bm[3, 7].cpu().numpy(), B1.astype(f))
+    sq = rn(B, N, n, n)
+    Cxx = dev(np.einsum("btij,btkj->btik", sq, sq) + 0.5 * np.eye(n, dtype=f))
+    su = rn(B, N, m, m)
+    Cuu = dev(np.einsum("btij,btkj->btik", su, su) + 0.5 * np.eye(m, dtype=f))
+    Cux = dev(0.1 * rn(B, N, m, n))
+    c0x, c0u = dev(rn(B, N, n)), dev(rn(B, N, m))
+    Rr, Qr = dev((0.05 * np.eye(m, dtype=f))[None]), dev((0.3 * np.eye(n, dtype=f))[None])
+    zx, zu, lx, lu = dev(rn(B, N, n)), dev(rn(B, N, m)), dev(0.1 * rn(B, N, n)), dev(0.1 * rn(B, N, m))
+    act = np.ones(B, dtype=np.int32); act[2] = 0
+    act = dev(act)
+    out = {}
+    for lin in (None, (capi.MODEL_DI, par)):
+        for fused in (False, True):
+            K = torch.full((B, N, m, n), 7.0, dtype=tdt, device="cuda")
+            k = torch.full((B, N, m), 7.0, dtype=tdt, device="cuda")
+            st = torch.zeros(B, dtype=torch.int32, device="cuda")
+            rec = torch.full((capi.ff_record_elems(B, N, n, m),), float("nan"), dtype=tdt, device="cuda")
+            g = capi.Kernels.gain_args(A, Bm, Cxx, Cuu, K, None, None, None, Cux=Cux, solve_mode=mode, status=st, active=act, rec=rec, lin=lin)
+            if fused:
+                ff = capi.Kernels.ff_args(A, Bm, c0x, c0u, K, None, None, None, k, Qr=Qr, Rr=Rr, xhat=xhat, uhat=uhat, zx=zx, lx=lx, zu=zu, lu=lu,
+                                          solve_mode=mode, active=act, rec=rec, lin=lin)
+                hk.riccati_gain_ff(g, ff, dtype)
+            else:
+                hk._call("riccati_gain", dtype, g, None)
+            torch.cuda.synchronize()
+            assert int(st.max()) == 0
+            out[(lin is not None, fused)] = (K.cpu().numpy(), rec.cpu().numpy(), k.cpu().numpy())
+    for fused in (False, True):
+        (K0, r0, k0), (K1, r1, k1) = out[(False, fused)], out[(True, fused)]
+        assert np.isfinite(K0).all() and np.abs(K0[0]).max() > 0 and np.array_equal(K0[2], np.full_like(K0[2], 7.0))
+        used = n * n + 2 * n * m + m * m                          # words of a record; an odd count is padded by one word nobody writes
+        stride = (used + 1) & ~1
+        r0, r1 = r0.reshape(-1, stride)[:, :used], r1.reshape(-1, stride)[:, :used]
+        assert np.array_equal(np.isnan(r0), np.isnan(r1)) and (~np.isnan(r0)).sum() >= (B - 1) * (N - 1) * used
+        r0, r1 = np.nan_to_num(r0), np.nan_to_num(r1)
+        if dtype == "f64":
+            assert np.array_equal(K0, K1), f"K differs (fused={fused}): {np.abs(K0 - K1).max():.3e}"
+            bad = np.argwhere(r0 != r1)
+            assert bad.size == 0, f"records differ (fused={fused}) at {bad[:5].tolist()}: {r0[tuple(bad[0])]!r} vs {r1[tuple(bad[0])]!r}"
+            if fused:
+                assert np.isfinite(k0).all() and np.array_equal(k0, k1), f"k differs: {np.abs(k0 - k1).max():.3e}"
+        else:
+            rel = lambda x, y: float(np.abs(x - y).max() / max(1.0, np.abs(x).max()))   # noqa: E731
+            assert rel(K0, K1) < 1e-5 and rel(r0, r1) < 1e-5, f"fused={fused}: K {rel(K0, K1):.2e} records {rel(r0, r1):.2e}"
+            if fused:
+                assert np.isfinite(k0).all() and rel(k0, k1) < 1e-5, f"k {rel(k0, k1):.2e}"
+
+
 @pytest.mark.parametrize("nb_dim,nb_deriv", [(1, 3), (2, 3), (2, 1), (3, 1)])
 def test_further_state_control_dimensions(dual, nb_dim, nb_deriv):
     """(x_dim, u_dim) beyond the notebooks' four systems: every get_double_integrator_AB(nb_dim <= 3, nb_deriv <= 3) system
