@@ -71,7 +71,7 @@ def pmc_traffic(kind):
     return total if found else None
 
 
-def algorithmic_bytes(n, m, N, w, has_x, has_u, lti, hess_shared, records, gain_ff=False):
+def algorithmic_bytes(n, m, N, w, has_x, has_u, lti, hess_shared, records, gain_ff=False, structured=False):
     """HBM bytes per trajectory per launch that each kernel family MUST move in the layout in use (each distinct array
     once; stride-0 shared tables cost nothing per trajectory):
       hess_shared : Cxx, Cuu are batch-shared [N,.,.] tables (Engine._shared_hessian) -> not counted;
@@ -81,28 +81,33 @@ def algorithmic_bytes(n, m, N, w, has_x, has_u, lti, hess_shared, records, gain_
                     K out only (writing them is its own overhead), ff with what it reads.
       gain_ff     : the first feed-forward pass of an outer iteration rides on the gain pass (isls_riccati_gain_ff_*): that
                     launch is credited with the pass's vectors as well (c0, the regularised blocks in, k out) -- not with
-                    the operators, which it never reads back."""
-    ab = 0 if lti else n * n + n * m
+                    the operators, which it never reads back.
+      structured  : A, B are the linearisation of a model whose structure the passes know (isls_gain_args.lin_on /
+                    isls_ff_args.lin_on: the double integrator): the gain pass does not read A, B, a feed-forward pass
+                    reads [K | fac] of a record (mn + m^2 words) instead of all of it."""
+    ab = 0 if (lti or structured) else n * n + n * m
     hess = 0 if hess_shared else n * n + m * m
     reg = (3 * n if has_x else 0) + (3 * m if has_u else 0)            # xhat/uhat, z, lambda of the regularised blocks
     gain = ab + hess + m * n + (0 if records else m * n + 2 * m * m)   # A,B,(Cxx,Cuu) in; K (,Qux,Quu,fac) out
     if gain_ff:
         gain += (n + m) + reg + m
     ops = (n * n + 2 * n * m + m * m) if records else (ab + 2 * m * n + 2 * m * m)
-    ff = ops + (n + m) + reg + m                                       # operators, c0, reg in; k out
+    ops_ff = (m * n + m * m) if (records and structured) else ops
+    ff = ops_ff + (n + m) + reg + m                                    # operators, c0, reg in; k out
     ro = m * n + m + (n + m) + ((2 * n if has_x else 0) + (2 * m if has_u else 0)) + (n + m)   # K,k,nominal,z,l in; x,u out
     admm = (5 * n if has_x else 0) + (5 * m if has_u else 0)          # x,z,l in; z,l out
     prep = ops + m * n                                                 # operators in; G out (once per gain pass)
     return [w * N * v for v in (gain, ff, ro, admm, prep)]
 
 
-def iteration_bytes(n, m, N, w, hess_shared, has_x=True, has_u=True):
+def iteration_bytes(n, m, N, w, hess_shared, has_x=True, has_u=True, ab_shared=False):
     """SURVEY 8(d) official figure: bytes_traj = w*N*[2n^2 + 2nm + m^2 + m + 7(n+m)] (fully fused ideal).  Of the 7(n+m), 3(n+m)
     are cx,cu in, xhat,uhat in and out; 4(n+m) are z, lambda in and out, which exist only for the constrained blocks (config 2
     constrains u alone: 4m); the n^2 + m^2 of Cxx, Cuu are dropped when they are batch-shared tables ("drop the
     Cxx,Cuu terms when they are shared")."""
     zl = 4 * ((n if has_x else 0) + (m if has_u else 0))
-    return w * N * (2 * n * n + 2 * n * m + m * m + m + 3 * (n + m) + zl - (n * n + m * m if hess_shared else 0))
+    ab = 0 if ab_shared else n * n + n * m                     # A, B: nothing per trajectory when they are the model's constants
+    return w * N * (n * n + n * m + ab + m * m + m + 3 * (n + m) + zl - (n * n + m * m if hess_shared else 0))
 
 
 def spawn_ranks(n_gpus):
@@ -262,6 +267,32 @@ def main():
     red_host = xch.finish().cpu().numpy()
     hess_shared = bool(eng._shared_hessian())
 
+    # ---- the same workload in the GENERAL layout: time-varying A_t, B_t per trajectory read from HBM by the gain pass, whole
+    # records by the feed-forward passes, A_t, B_t rewritten by every step -- what any model that is not a double integrator
+    # (or a caller's get_AB) runs; the timed region above is the product's default path, which recognises the model
+    structured = eng.ff_lin(eng.ff_record()) is not None
+    general_it_per_s = None
+    if structured:
+        eng.use_model_structure = False
+        step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        xch.finish()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dg = time.perf_counter() - tg
+        if dist is not None:
+            tg_ = torch.tensor([dg], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
+            dist.all_reduce(tg_, op=dist.ReduceOp.MAX)
+            dg = float(tg_.item())
+        general_it_per_s = world * args.steps / dg
+        eng.use_model_structure = True
+
     # ---- the same workload with A,B shared over batch and time (stride-0 views; SURVEY 8(d): "report both") ----
     lti_it_per_s = None
     if not args.lti:
@@ -311,7 +342,7 @@ def main():
         gain_ff = fam[1][1] < fam[2][1]                         # fewer ff launches than rollouts: the first pass rode on the gain pass
         has_x, has_u = eng.zx is not None, eng.zu is not None
         abytes = algorithmic_bytes(n, m, N, w, has_x=has_x, has_u=has_u, lti=args.lti, hess_shared=hess_shared, records=records,
-                                   gain_ff=gain_ff)
+                                   gain_ff=gain_ff, structured=structured)
         nseg_ff = max(1, int(eng._outer_args.ff.seg.nseg))
         abytes[4] = abytes[4] * (nseg_ff - 1) / nseg_ff          # the operators cover every segment but the last
         sampled = len(range(0, args.steps, EVENT_PERIOD))
@@ -319,7 +350,7 @@ def main():
         default_workload = (B, N, J, L) == (4096, 100, 5, 20) and not args.lti
         avg_ms = fam[dom][0] / max(1, fam[dom][1])
         achieved = abytes[dom] * B / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        it_bytes = iteration_bytes(n, m, N, w, hess_shared, has_x=has_x, has_u=has_u) * B
+        it_bytes = iteration_bytes(n, m, N, w, hess_shared, has_x=has_x, has_u=has_u, ab_shared=structured or args.lti) * B
         # every kernel family against the same HBM figure (algorithmic bytes / event-timed launch) with the PMC-measured
         # traffic of the committed profile next to it: the rollout is issue bound, the feed-forward pass is the one that streams
         families = {}
@@ -337,7 +368,12 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config2: 3-D double integrator iLQR-ADMM (DP form), box constraint on u",
                        "batch_per_gpu": B, "horizon": N, "x_dim": n, "u_dim": m, "admm_iters_J": J,
-                       "line_search_L": L, "layout": "LTI stride-0 A,B" if args.lti else "time-varying A,B per trajectory",
+                       "line_search_L": L,
+                       "layout": ("LTI stride-0 A,B" if args.lti else
+                                  ("double integrator recognised (isls.models.LTI -> ISLS_MODEL_DI): Riccati passes on the model's structure, "
+                                   "A,B linearised once, not read per step; the general layout is general_ab_iterations_per_s" if structured
+                                   else "time-varying A,B per trajectory")),
+                       "general_ab_iterations_per_s": general_it_per_s,   # time-varying A_t,B_t per trajectory read from HBM, rewritten every step
                        "cost_hessians": ("batch-shared [N,n,n] / [N,m,m] tables written once (via-point cost with a shared Q and rho; "
                                          "SURVEY 8d: Cxx,Cuu terms dropped)" if hess_shared else "per trajectory [B,N,n,n]"),
                        "early_exit": False, "lti_stride0_layout_iterations_per_s": lti_it_per_s,

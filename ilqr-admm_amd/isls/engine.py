@@ -141,7 +141,7 @@ class Engine:
         """Built-in forward model (ISLS_MODEL_*); par is [P] (shared) or [B,P] (per trajectory)."""
         self.model, self.model_par = int(model_id), self._t(par)
         self._outer_args = None
-        self._ab_made = None                                   # A, Bm no longer belong to the model in use
+        self._ab_made = self._ab_static = None                 # A, Bm no longer belong to the model in use
 
     def set_quadratic_cost(self, zs, Qs, seq, u_std):
         """Via-point quadratic cost (Base.set_quadratic_cost, isls/base.py:81-89); zs [nvia,n] or [B,nvia,n]."""
@@ -259,9 +259,13 @@ class Engine:
                                    cost_par=self.cost_par, q_nonzero=self.q_nonzero, stream=_stream_ptr())
 
     def linearize(self):
+        # a state-independent model (double integrator, dense LTI) has ONE linearisation: it is written for every trajectory,
+        # active or not, and advance() then leaves A, Bm alone for as long as they stay the model's
+        static = self.model in (capi.MODEL_DI, capi.MODEL_LTI)
         self.kern.linearize(self.model, self.model_par, self.xhat, self.uhat, self.A, self.Bm,
-                            active=self.outer_active, stream=_stream_ptr())
+                            active=None if static else self.outer_active, stream=_stream_ptr())
         self._mark_ab_made()
+        self._ab_static = self._ab_made if static else None
 
     # ---- whose A, Bm the buffers hold: the feed-forward passes may use the model's structure only for the model's own
     # linearisation (isls_ff_args.lin_on), never for a caller's A, B
@@ -272,6 +276,12 @@ class Engine:
         """A, Bm were written by somebody else (AB setter, get_AB callback): the dense records are the only valid form.
         A cached isls_outer_args block keeps its pointers; run_outer() rewrites its hint fields when this state has changed."""
         self._ab_made = None
+        self._ab_static = None
+
+    def _ab_is_static(self):
+        """A, Bm hold the one linearisation of a state-independent model, written for every trajectory"""
+        st = getattr(self, "_ab_static", None)
+        return st is not None and st == (self.model, self.A.data_ptr(), self.Bm.data_ptr())
 
     def _apply_ff_lin(self, blocks, rec):
         """(re)write the hint fields of marshalled isls_gain_args / isls_ff_args blocks for the state of A, Bm now"""
@@ -284,7 +294,7 @@ class Engine:
         """(model id, parameters) for isls_ff_args.lin_on, or None: the packed records are in use, A and Bm are what
         isls_linearize wrote into the buffers the engine holds now, for the model set now, and the model is one whose
         structure the record pass knows (ISLS_FF_LEAN=0 switches the form off)."""
-        if rec is None or not self.fast_dims or os.environ.get("ISLS_FF_LEAN", "1") == "0":
+        if rec is None or not self.fast_dims or not getattr(self, "use_model_structure", True) or os.environ.get("ISLS_FF_LEAN", "1") == "0":
             return None
         if self.model not in (capi.MODEL_DI, capi.MODEL_ARM3R) or self.model_par is None:
             return None
@@ -425,7 +435,7 @@ class Engine:
                            iters=self.admm_iters, x_sets=self.x_sets, x_col0=self.x_col0, x_work=self.x_work,
                            u_sets=self.u_sets, u_col0=self.u_col0, u_work=self.u_work)
         self._outer_args = capi.OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=0, begin_done=int(bool(begin_done)))
-        self._outer_rec, self._outer_lin_state = rec, getattr(self, "_ab_made", None)
+        self._outer_rec, self._outer_lin_state = rec, (getattr(self, "_ab_made", None), getattr(self, "use_model_structure", True))
         self._advance_args = None
         self._outer_args.log = capi._ptr(log)
         self._outer_args.outer_active = capi._ptr(self.outer_active)
@@ -436,7 +446,7 @@ class Engine:
         """gain -> J x [ff -> rollout/line-search -> ADMM update] on the current stream (no host sync)."""
         fn = getattr(library(), f"isls_ilqr_admm_outer_{self.sfx}")
         fn.restype = ctypes.c_int
-        state = getattr(self, "_ab_made", None)
+        state = (getattr(self, "_ab_made", None), getattr(self, "use_model_structure", True))
         if state != getattr(self, "_outer_lin_state", ()):     # A, Bm changed hands since the block was marshalled / last run
             self._apply_ff_lin((self._outer_args.gain, self._outer_args.ff), self._outer_rec)
             self._outer_lin_state = state
@@ -468,6 +478,8 @@ class Engine:
         trajectories still iterating.  Pair it with build_outer(..., begin_done=True).  `linearize=False` leaves A, B alone (a
         shared LTI pair).  The cost Hessians must be the batch-shared tables (written once by expand())."""
         K = capi.Kernels
+        if linearize and getattr(self, "use_model_structure", True) and self._ab_is_static():
+            linearize = False                                  # the model's one linearisation is in place: nothing to rewrite
         key = (float(tol_cost), float(tol_osc), bool(linearize))
         if getattr(self, "_advance_args", None) is None or self._advance_args[0] != key:
             if not self._shared_hessian():

@@ -285,3 +285,10 @@ def test_bench_byte_formulas():
     assert b.iteration_bytes(n, m, N, w, False, has_x=True, has_u=True) == w * N * (2 * n * n + 2 * n * m + m * m + m + 7 * (n + m))   # 146 400 B
     gain, ff, ro, admm, prep = b.algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=False, hess_shared=True, records=True, gain_ff=True)
     assert ro * B == 147_456_000 and ff * B == 334_233_600 and gain * B == 304_742_400
+    # the double integrator recognised (isls_gain_args.lin_on / isls_ff_args.lin_on): no A, B for the gain pass (36 + 18 words per
+    # step less), [K | fac] = 27 of a record's 81 words for a feed-forward pass, and no A, B in the iteration's figure
+    gain_s, ff_s, ro_s, _, _ = b.algorithmic_bytes(n, m, N, w, has_x=False, has_u=True, lti=False, hess_shared=True, records=True, gain_ff=True,
+                                                   structured=True)
+    assert ro_s == ro and (ff - ff_s) == w * N * 54 and (gain - gain_s) == w * N * 54
+    assert ff_s * B == 157_286_400 and gain_s * B == 127_795_200
+    assert b.iteration_bytes(n, m, N, w, True, has_x=False, has_u=True, ab_shared=True) * B == 373_555_200 - w * N * 54 * B == 196_608_000
