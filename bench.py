@@ -270,7 +270,7 @@ def main():
     # ---- the same workload in the GENERAL layout: time-varying A_t, B_t per trajectory read from HBM by the gain pass, whole
     # records by the feed-forward passes, A_t, B_t rewritten by every step -- what any model that is not a double integrator
     # (or a caller's get_AB) runs; the timed region above is the product's default path, which recognises the model
-    structured = eng.ff_lin(eng.ff_record()) is not None
+    structured = bool(eng._outer_args.ff.lin_on)               # what the timed region ran with
     general_it_per_s = None
     if structured:
         eng.use_model_structure = False

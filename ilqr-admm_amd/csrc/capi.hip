@@ -52,6 +52,9 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
         (rc = launch_outer_begin<T>(ad.B, ad.N, ad.n, ad.m, ad.active, a.outer_active, ad.lx, ad.lu, ad.res_prev, ad.iters, s)) != ISLS_OK)
         return rc;
     bool ff_done = false;                                      // the gain pass ran the first feed-forward pass as well
+    // the gain pass writes the records in the layout its hint selects and the feed-forward passes read them in theirs
+    if (a.J > 0 && a.gain.rec && a.ff.rec == a.gain.rec && (a.gain.lin_on != 0) != (a.ff.lin_on != 0)) return ISLS_ERR_ARG;
+    if (a.ff.lin_on && ff_seg_enabled(a.ff.seg)) return ISLS_ERR_UNSUPPORTED;   // the segment operators need the dense records
     if (!a.skip_gain) {
         {
             ScopedTimer tm(tmg, 0, s);

@@ -283,7 +283,7 @@ template <typename T>
 int launch_ff_generic(const isls_ff_args &a, hipStream_t s)
 {
     if (!dims_generic(a.n, a.m)) return ISLS_ERR_UNSUPPORTED;
-    if (a.rec || a._pad > 1 || a.Qr_term || !a.A.p || !a.Bm.p || !a.K || !a.Quu || !a.fac || !a.Qux) return ISLS_ERR_UNSUPPORTED;
+    if (a.rec || a.lin_on || a._pad > 1 || a.Qr_term || !a.A.p || !a.Bm.p || !a.K || !a.Quu || !a.fac || !a.Qux) return ISLS_ERR_UNSUPPORTED;
     GenFfP<T> p;
     p.B = a.B; p.N = a.N; p.n = a.n; p.m = a.m; p.mode = a.solve_mode;
     p.A = View<T>(a.A); p.Bm = View<T>(a.Bm); p.c0x = View<T>(a.c0x); p.c0u = View<T>(a.c0u); p.Qr = View<T>(a.Qr); p.Rr = View<T>(a.Rr);

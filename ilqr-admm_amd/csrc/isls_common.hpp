@@ -192,6 +192,9 @@ __device__ __forceinline__ float py_mod(float a, float b)
 // 8-byte loads at a 64.8 KB stride: the structured form then ran no faster than the dense one).  Other pairs: none.
 __host__ __device__ constexpr int rec_model_words(int n, int m) { return (n == 9 && m == 3) ? 6 : 0; }
 __host__ __device__ constexpr int rec_stride(int n, int m) { return (n * n + 2 * n * m + m * m + rec_model_words(n, m) + 1) & ~1; }
+// The lean layout (isls_gain_args.lin_on / isls_ff_args.lin_on): only the tail [K | fac | model words] of a record, at this stride
+// (the same buffer: isls_ff_record_elems covers the dense layout, the lean one uses a prefix of it).
+__host__ __device__ constexpr int rec_lean_stride(int n, int m) { return (m * n + m * m + rec_model_words(n, m) + 1) & ~1; }
 
 // Launch wrappers implemented one per .hip file; each returns ISLS_OK / ISLS_ERR_*.
 // ff != nullptr: the pass may also run the first feed-forward pass (same records, time-invariant Qr / Rr); *did_ff tells

@@ -114,10 +114,14 @@ __device__ __forceinline__ bool chol_upper_rd(const T (&A)[M][M], T (&U)[M][M], 
 // dense form that is left out adds an exact zero, and the ones that stay are written in the dense form's order and source
 // form.  fp64: bit-identical to the dense kernel (finite operands; tests compare K, records and k bit by bit).  fp32: equal to
 // rounding only -- there the compiler packs some two-term sums of the DENSE kernel into unfused v_pk_mul / v_pk_add pairs.
-template <typename T, int NX, int NU, int D, int MODE, bool FF, bool REC, bool ARR, int LIN = 0>
+// RL (isls_gain_args.lin_on): only the tail [K | fac | model words] of every record leaves for HBM, at its own dense stride
+// rec_lean_stride -- the layout the model-structured feed-forward pass reads (the [Phi | B] blocks nobody would read are 54 of
+// 81 words at n = 6, m = 3: 177 MB of stores per launch at the headline size).  The record IMAGE in LDS keeps its full form.
+template <typename T, int NX, int NU, int D, int MODE, bool FF, bool REC, bool ARR, int LIN = 0, bool RL = (LIN == 1)>
 __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T> p)
 {
     static_assert(LIN == 0 || NX == 2 * NU, "double integrator: n = 2 d, m = d");
+    static_assert(!RL || (REC && !ARR), "lean records: record form without the Quu / fac / Qux arrays");
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
     constexpr int V_OFF = 0, AB_OFF = V_OFF + NX * NX, Q_OFF = AB_OFF + NX * W, K_OFF = Q_OFF + NU * W;
     constexpr int DUMP_OFF = K_OFF + NU * NX;              // W words that absorb the LDS writes of lanes with nothing to publish
@@ -320,7 +324,10 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
     // lane-linear plan of the image's way out: 16-byte pair q = lane + 64 j of the TPW*RW record words (the last pair again
     // for surplus lanes: same words to the same address), and pair / word e of the slots' K blocks for the K array
     typedef T V2 __attribute__((ext_vector_type(2)));
-    constexpr int NPAIR = TPW * RW / 2, JP = (NPAIR + kWave - 1) / kWave;
+    constexpr int RSW = RL ? rec_lean_stride(NX, NU) : RW;     // words of a record that leave for HBM, = its stride there
+    constexpr int RSRC = RL ? RK : 0;                          // the first of them in the image
+    static_assert(RSRC % 2 == 0 && RSRC + RSW <= RW, "record tail: pair-aligned, inside the image");
+    constexpr int NPAIR = TPW * RSW / 2, JP = (NPAIR + kWave - 1) / kWave;
     constexpr bool KPAIRS = (NU * NX) % 2 == 0 && RK % 2 == 0;
     constexpr int KU = KPAIRS ? NU * NX / 2 : NU * NX, JK = (TPW * KU + kWave - 1) / kWave;   // K pieces per slot / loads per lane
     int kso[JK];                                               // image word of the lane's K piece
@@ -336,10 +343,14 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
         kso[j] = sl * RW + RK + pc * (KPAIRS ? 2 : 1);
         kgo[j] = (int64_t)(ok ? bk : bsh) * N * (NU * NX) + pc * (KPAIRS ? 2 : 1);
     }
-    int fw[JP];                                                // image word of the lane's j-th record pair
+    int fw[JP], fd[JP];                                        // image word of the lane's j-th record pair; its word in the step's run
 #pragma unroll
-    for (int j = 0; j < JP; ++j) { const int pq = lane + kWave * j; fw[j] = 2 * (pq < NPAIR ? pq : NPAIR - 1); }
-    T *const recg = REC ? p.rec + (int64_t)bx * N * (TPW * RW) : nullptr;   // the wavefront's records, step 0
+    for (int j = 0; j < JP; ++j) {
+        const int pq = lane + kWave * j;
+        fd[j] = 2 * (pq < NPAIR ? pq : NPAIR - 1);
+        fw[j] = (fd[j] / RSW) * RW + RSRC + fd[j] % RSW;       // (dense records: fw == fd)
+    }
+    T *const recg = REC ? p.rec + (int64_t)bx * N * (TPW * RSW) : nullptr;   // the wavefront's records, step 0
 
     // The image of a step is read back into fl / fk behind its sync (c) and leaves for HBM during the NEXT step, one store
     // between two blocks of that step's arithmetic: a wavefront waits while a store's data drains (the CU moves ~7-16 B per
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
     auto send = [&](int tq, int j) {                           // j-th of the JP + JK stores of step tq's image
         if (j < JP) {
             if constexpr (REC) {
-                V2 *dr = reinterpret_cast<V2 *>(recg + (int64_t)tq * (TPW * RW) + fw[j < JP ? j : 0]);
+                V2 *dr = reinterpret_cast<V2 *>(recg + (int64_t)tq * (TPW * RSW) + fd[j < JP ? j : 0]);
                 if constexpr (ISLS_NT_GAIN_ST) st_stream(dr, fl[j < JP ? j : 0]);
                 else *dr = fl[j < JP ? j : 0];
             }
@@ -778,11 +789,14 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     p.rev = rev_mode ? 1 : 0;
     // model-structured form (isls_gain_args.lin_on): the double integrator, on the record forms the drivers use; a hint -- A
     // and Bm are complete, so any other case runs the dense kernel (ISLS_GAIN_LEAN=0 switches the form off)
-    static const bool lean_env = [] { const char *e = getenv("ISLS_GAIN_LEAN"); return !e || atoi(e) != 0; }();
-    bool lin_di = false;
+    if (ff && ff->rec == a.rec && a.rec && (ff->lin_on != 0) != (a.lin_on != 0)) return ISLS_ERR_ARG;   // one layout for writer and reader
+    // lin_on also selects the LEAN record layout, which the feed-forward passes of the same hint read: no silent fall-back
+    bool lin_di = false, lean_arm = false;
     if (a.lin_on) {
-        if (a.lin_model == ISLS_MODEL_DI) { if (a.n != 2 * a.m || !a.lin_par) return ISLS_ERR_ARG; lin_di = lean_env && a.rec && !a.Qux; }
-        else if (a.lin_model != ISLS_MODEL_ARM3R) return ISLS_ERR_UNSUPPORTED;      // the arm's records carry J; its gain pass is the dense one
+        if (!a.rec || a.Quu || a.fac || a.Qux) return ISLS_ERR_UNSUPPORTED;        // record form without the arrays only
+        if (a.lin_model == ISLS_MODEL_DI) { if (a.n != 2 * a.m || !a.lin_par) return ISLS_ERR_ARG; lin_di = true; }
+        else if (a.lin_model == ISLS_MODEL_ARM3R) { if (a.n != 9 || a.m != 3) return ISLS_ERR_ARG; lean_arm = true; }   // dense arithmetic, lean records
+        else return ISLS_ERR_UNSUPPORTED;
     }
     p.lin_par = (const T *)a.lin_par; p.lin_par_sb = a.lin_par_sb;
     // the first feed-forward pass rides along when it would run on this pass's records with time-invariant Qr / Rr rows
@@ -810,7 +824,10 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
             }                                                                               \
         } else if (a.rec && !a.Qux) {                                                       \
             if constexpr (NX_ == 2 * NU_) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, false); else LAUNCH_G(NX_, NU_, MODE_, false, true, false); } \
-            else LAUNCH_G(NX_, NU_, MODE_, false, true, false);                             \
+            else if constexpr (NX_ == 9 && NU_ == 3) {                                      \
+                if (lean_arm) hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, false, true, false, 0, true>), dim3(grid), dim3(64), 0, s, p); \
+                else LAUNCH_G(NX_, NU_, MODE_, false, true, false);                         \
+            } else LAUNCH_G(NX_, NU_, MODE_, false, true, false);                           \
         }                                                                                   \
         else if (a.rec) LAUNCH_G(NX_, NU_, MODE_, false, true, true);                       \
         else LAUNCH_G(NX_, NU_, MODE_, false, false, true);                                 \

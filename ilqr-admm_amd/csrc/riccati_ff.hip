@@ -307,6 +307,7 @@ int launch_ff(const isls_ff_args &a, hipStream_t s)
     if (a.Qr.p && (!a.zx || !a.lx)) return ISLS_ERR_ARG;
     if (a.Rr.p && (!a.zu || !a.lu)) return ISLS_ERR_ARG;
     if (a.solve_mode != ISLS_SOLVE_CHOL && a.solve_mode != ISLS_SOLVE_INV) return ISLS_ERR_ARG;
+    if (a.lin_on && !a.rec) return ISLS_ERR_ARG;              // the hint describes the records' layout
     // per-lane offsets inside one workgroup are 32-bit element counts
     if ((int64_t)a.N * a.n * a.n * 64 >= ((int64_t)1 << 31) || a.A.sb * 64 >= ((int64_t)1 << 31) || a.Bm.sb * 64 >= ((int64_t)1 << 31))
         return ISLS_ERR_UNSUPPORTED;

@@ -279,12 +279,13 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     static_assert(LIN != LIN_ARM3R || (NX == 9 && NU == 3), "planar 3R arm: n = 9, m = 3");
     constexpr bool LEAN = LIN != LIN_NONE;
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
-    constexpr int RW = rec_stride(NX, NU);                     // words between the records of consecutive slots in HBM
-    constexpr int SRC_OFF = LEAN ? NX * NX + NX * NU : 0;      // first word of a record the pass reads (even: 16-byte pairs)
+    // the structured forms read the LEAN records the gain pass writes under the same hint: [K | fac | model words] at stride
+    // rec_lean_stride; the dense form the whole records at rec_stride
+    constexpr int RW = LEAN ? rec_lean_stride(NX, NU) : rec_stride(NX, NU);   // words between the records of consecutive slots in HBM
+    constexpr int SRC_OFF = 0;
     constexpr int NJ = LIN == LIN_ARM3R ? 6 : 0;               // the arm's J behind fac (rec_model_words)
     static_assert(NJ <= rec_model_words(NX, NU), "the records of this pair carry no model words");
-    constexpr int SW = LEAN ? ((NU * NX + NU * NU + NJ + 1) & ~1) : RW;   // words of a record staged through LDS
-    static_assert(SRC_OFF % 2 == 0 && SRC_OFF + SW <= RW, "record tail must be pair-aligned and inside the record");
+    constexpr int SW = RW;                                     // words of a record staged through LDS
     constexpr int PHI_OFF = 0, B_OFF = PHI_OFF + NX * NX, K_OFF = LEAN ? 0 : B_OFF + NX * NU, FAC_OFF = K_OFF + NU * NX;
     constexpr int J_OFF = FAC_OFF + NU * NU;
     // slot: record (tail: K | fac | J) | d[W] | c0u[NU] | v[NX] | qu[NU] | dump pair
@@ -581,12 +582,6 @@ static bool v2_on_()
 #ifndef ISLS_FF2_LEAN_DEPTH
 #define ISLS_FF2_LEAN_DEPTH 3      // ring depth of the model-structured form (a third of the record words per entry)
 #endif
-static bool lean_on_()
-{
-    static const bool on = [] { const char *e = getenv("ISLS_FF_LEAN"); return !e || atoi(e) != 0; }();
-    return on;
-}
-
 // the one-hand-off kernel in the form `lin` selects (the structured forms exist for the dimensions their models have)
 template <typename T, int NX, int NU, int D, int DL, int OCC, int MODE>
 static void launch_ffrec2(int lin, dim3 grid, hipStream_t s, const FfRecP<T> &p)
@@ -636,16 +631,16 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
 #define ISLS_FF2_SEG_DEPTH 2
 #endif
     const bool v2_on = v2_on_();
-    // model-structured form (isls_ff_args.lin_on): a hint -- the records are complete, so every case the one-hand-off kernel
-    // does not take (time-varying weights, ISLS_FF_V2 = 0, ISLS_FF_LEAN = 0) runs the dense form; a request that contradicts
-    // itself is an error
+    // model-structured form (isls_ff_args.lin_on): the records are the LEAN ones the gain pass wrote under the same hint, which
+    // only the one-hand-off kernel reads -- time-varying weights, the time-parallel form (its operators come from the dense
+    // records) or ISLS_FF_V2 = 0 are ISLS_ERR_UNSUPPORTED, not a fall-back
     int lin = LIN_NONE;
     if (a.lin_on) {
         if (a.lin_model == ISLS_MODEL_DI) { if (a.n != 2 * a.m) return ISLS_ERR_ARG; lin = LIN_DI; }
         else if (a.lin_model == ISLS_MODEL_ARM3R) { if (a.n != 9 || a.m != 3) return ISLS_ERR_ARG; lin = LIN_ARM3R; }
         else return ISLS_ERR_UNSUPPORTED;
         if (!a.lin_par) return ISLS_ERR_ARG;
-        if (!(rowc && v2_on && lean_on_())) lin = LIN_NONE;
+        if (!(rowc && v2_on) || segmented) return ISLS_ERR_UNSUPPORTED;
     }
     p.lin_par = (const T *)a.lin_par; p.lin_par_sb = a.lin_par_sb;
 #define LAUNCH2(NX_, NU_, MODE_)                                                                                        \

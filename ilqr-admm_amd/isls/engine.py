@@ -283,22 +283,31 @@ class Engine:
         st = getattr(self, "_ab_static", None)
         return st is not None and st == (self.model, self.A.data_ptr(), self.Bm.data_ptr())
 
-    def _apply_ff_lin(self, blocks, rec):
+    def _apply_ff_lin(self, blocks, rec, seg=None):
         """(re)write the hint fields of marshalled isls_gain_args / isls_ff_args blocks for the state of A, Bm now"""
-        lin = self.ff_lin(rec)
+        lin = self.ff_lin(rec, seg)
         for a in blocks:
             capi.Kernels._set_lin(a, lin, self.B, self.dtype)
         return lin
 
-    def ff_lin(self, rec):
-        """(model id, parameters) for isls_ff_args.lin_on, or None: the packed records are in use, A and Bm are what
-        isls_linearize wrote into the buffers the engine holds now, for the model set now, and the model is one whose
-        structure the record pass knows (ISLS_FF_LEAN=0 switches the form off)."""
-        if rec is None or not self.fast_dims or not getattr(self, "use_model_structure", True) or os.environ.get("ISLS_FF_LEAN", "1") == "0":
+    def ff_lin(self, rec, seg=None):
+        """(model id, parameters) for isls_gain_args.lin_on / isls_ff_args.lin_on, or None.  The hint makes the gain pass write
+        the LEAN records and the feed-forward passes read them, so it is given only when every pass on these records can take
+        the structured form: the packed records are in use, A and Bm are what isls_linearize wrote into the buffers the engine
+        holds now for the model set now, the model is one whose structure the passes know, the ADMM weights are the same at
+        every step (a terminal block apart), and the passes run sequentially (`seg`: the time-parallel form builds its
+        operators from the dense records).  ISLS_FF_LEAN=0 / use_model_structure = False switch the forms off."""
+        if rec is None or seg is not None or not self.fast_dims or not getattr(self, "use_model_structure", True):
+            return None
+        if os.environ.get("ISLS_FF_LEAN", "1") == "0" or os.environ.get("ISLS_FF_V2", "1") == "0":
             return None
         if self.model not in (capi.MODEL_DI, capi.MODEL_ARM3R) or self.model_par is None:
             return None
         if getattr(self, "_ab_made", None) != (self.model, self.A.data_ptr(), self.Bm.data_ptr()):
+            return None
+        inv = lambda W: W is None or W.ndim < 3 or W.shape[-3] == 1       # noqa: E731
+        Qr_ff, _ = self._ff_weights(rec)
+        if not (inv(self.Rr) and inv(Qr_ff)):
             return None
         return (self.model, self.model_par)
 
@@ -346,14 +355,31 @@ class Engine:
             self._ffrec = torch.zeros(capi.ff_record_elems(self.B, self.N, self.n, self.m), dtype=self.dtype, device=self.device)
         return self._ffrec
 
-    def gain(self, active=None, rec=None):
+    def gain(self, active=None, rec=None, seg=None, structured=True):
         """Gain pass; with `rec` the caller promises to run its feed-forward passes on the records, and Quu / fac / Qux
-        (which only those passes would read) are not written."""
+        (which only those passes would read) are not written.  `seg`: the segment plan those passes will use (ff_lin);
+        `structured=False`: the caller's passes cannot take the model-structured form (it hands them other weights)."""
         full = rec is None
+        lin = self.ff_lin(rec, seg) if structured else None
+        self._rec_layout = (None if rec is None else rec.data_ptr(), lin is not None)   # which records, lean or dense
         self.kern.riccati_gain(self.A, self.Bm, *self.hessians(), self.K, self.Quu if full else None,
                                self.fac if full else None, self.Qux if full else None,
                                Cux=self.Cux, solve_mode=self.solve_mode, status=self.status, active=active, rec=rec,
-                               lin=self.ff_lin(rec), stream=_stream_ptr())
+                               lin=lin, stream=_stream_ptr())
+
+    def rec_lin(self, rec, seg=None):
+        """The hint for a feed-forward pass on `rec` as the last gain pass left it: lean records need the structured form (and
+        raise when it does not apply any more), dense ones the dense form."""
+        if rec is None:
+            return None
+        ptr, lean = getattr(self, "_rec_layout", (None, False))
+        if ptr != rec.data_ptr() or not lean:
+            return None
+        lin = self.ff_lin(rec, seg)
+        if lin is None:
+            raise capi.IslsError("the gain pass wrote the records in the model-structured layout, which this feed-forward pass cannot "
+                                 "read (weights, segments or A, B changed since): run the gain pass again")
+        return lin
 
     def _ff_weights(self, rec):
         """(Qr, Qr_term) operands of a feed-forward pass: the terminal-block form on the packed records when it applies"""
@@ -367,7 +393,7 @@ class Engine:
         self.kern.riccati_ff(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                              Qr=Qr, Qr_term=Qr_term, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx,
                              zu=self.zu, lu=self.lu, solve_mode=self.solve_mode, active=active, seg=seg, rec=rec,
-                             lin=self.ff_lin(rec), stream=_stream_ptr())
+                             lin=self.rec_lin(rec, seg), stream=_stream_ptr())
 
     def rollout(self, L, flags=0, cost_all=None, active=None):
         self.kern.rollout_ls(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
@@ -414,16 +440,17 @@ class Engine:
         begin_done: the caller ends every outer iteration with `advance()`, which also makes the ADMM restart of the next one."""
         K = capi.Kernels
         rec = self.ff_record()
+        seg = self.ff_seg(ff_nseg)
         # with the records, nothing in this driver reads Quu / fac / Qux: the gain pass then skips those stores
         full = rec is None
         gain = K.gain_args(self.A, self.Bm, *self.hessians(), self.K, self.Quu if full else None, self.fac if full else None,
                            self.Qux if full else None, Cux=self.Cux, solve_mode=self.solve_mode, status=self.status,
-                           active=self.admm_active, rec=rec, lin=self.ff_lin(rec))
+                           active=self.admm_active, rec=rec, lin=self.ff_lin(rec, seg))
         Qr_ff, Qr_term = self._ff_weights(rec)
         ff = K.ff_args(self.A, self.Bm, self.c0x, self.c0u, self.K, self.Quu, self.fac, self.Qux, self.k,
                        Qr=Qr_ff, Qr_term=Qr_term, Rr=self.Rr, xhat=self.xhat, uhat=self.uhat, zx=self.zx, lx=self.lx, zu=self.zu,
-                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=self.ff_seg(ff_nseg), rec=rec,
-                       lin=self.ff_lin(rec))
+                       lu=self.lu, solve_mode=self.solve_mode, active=self.admm_active, seg=seg, rec=rec,
+                       lin=self.ff_lin(rec, seg))
         ro = K.rollout_args(self.model, self.model_par, self.K, self.k, self.xhat, self.uhat, self.alphas[:L],
                             self.Qtab, self.ztab, self.seq, self.u_std, self.xx, self.xu, best=self.best,
                             cost_new=self.cost_new, wq=self.wq, wr=self.wr, zx=self.zx, lx=self.lx, zu=self.zu,
@@ -435,7 +462,8 @@ class Engine:
                            iters=self.admm_iters, x_sets=self.x_sets, x_col0=self.x_col0, x_work=self.x_work,
                            u_sets=self.u_sets, u_col0=self.u_col0, u_work=self.u_work)
         self._outer_args = capi.OuterArgs(gain=gain, ff=ff, ro=ro, admm=admm, J=int(J), skip_gain=0, begin_done=int(bool(begin_done)))
-        self._outer_rec, self._outer_lin_state = rec, (getattr(self, "_ab_made", None), getattr(self, "use_model_structure", True))
+        self._outer_rec, self._outer_seg = rec, seg
+        self._outer_lin_state = (getattr(self, "_ab_made", None), getattr(self, "use_model_structure", True))
         self._advance_args = None
         self._outer_args.log = capi._ptr(log)
         self._outer_args.outer_active = capi._ptr(self.outer_active)
@@ -448,8 +476,10 @@ class Engine:
         fn.restype = ctypes.c_int
         state = (getattr(self, "_ab_made", None), getattr(self, "use_model_structure", True))
         if state != getattr(self, "_outer_lin_state", ()):     # A, Bm changed hands since the block was marshalled / last run
-            self._apply_ff_lin((self._outer_args.gain, self._outer_args.ff), self._outer_rec)
+            self._apply_ff_lin((self._outer_args.gain, self._outer_args.ff), self._outer_rec, self._outer_seg)
             self._outer_lin_state = state
+        if self._outer_rec is not None:                        # the driver's gain pass leaves the records in this layout
+            self._rec_layout = (self._outer_rec.data_ptr(), bool(self._outer_args.gain.lin_on))
         rc = fn(ctypes.byref(self._outer_args), ctypes.c_void_p(_stream_ptr()))
         if rc != capi.OK:
             raise capi.IslsError(f"isls_ilqr_admm_outer_{self.sfx} -> {rc}")

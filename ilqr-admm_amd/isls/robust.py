@@ -68,8 +68,9 @@ class ColumnSolver:
                     raise ValueError(f"project_{key} needs rho_{key}")
                 self.blocks[key]["W"] = W
         self.rec = e.ff_record()
-        e.gain(active=active, rec=self.rec)
-        self.seg = e.ff_seg()
+        self.seg = e.ff_seg()                                   # planned before the gain pass: it decides the records' layout
+        inv = lambda W: W is None or W.ndim < 3 or W.shape[-3] == 1                      # noqa: E731
+        e.gain(active=active, rec=self.rec, seg=self.seg, structured=inv(e.Qr) and inv(e.Rr))   # x_step hands e.Qr, e.Rr over as they are
         self.seg_cols = None
         if self.seg is not None:
             e.feedforward_prepare(self.seg, active=active, rec=self.rec)
@@ -110,7 +111,7 @@ class ColumnSolver:
             self._zero_zx, self._zero_zu = zz(e.n), zz(e.m)
             zc = lambda d: torch.zeros(self.C, e.B, e.N, d, dtype=e.dtype, device=e.device)   # noqa: E731
             self._zero_cx, self._zero_cu = (zc(e.n) if bx is None else None), (zc(e.m) if bu is None else None)
-        ff_kw = dict(Qr=e.Qr, Rr=e.Rr, solve_mode=e.solve_mode, active=act, rec=self.rec, lin=e.ff_lin(self.rec), stream=_stream_ptr())
+        ff_kw = dict(Qr=e.Qr, Rr=e.Rr, solve_mode=e.solve_mode, active=act, rec=self.rec, lin=e.rec_lin(self.rec, self.seg), stream=_stream_ptr())
         if self._columns_in_one_launch():
             # all C feed-forward passes as ONE launch (isls_ff_args ncol): the columns share the packed records, each has its
             # own targets z - lmb and its own k; the cost gradients act on column 0
@@ -148,7 +149,7 @@ class ColumnSolver:
         ff = K.ff_args(e.A, e.Bm, e.c0x, e.c0u, e.K, e.Quu, e.fac, e.Qux, self.kcol, Qr=e.Qr, Rr=e.Rr,
                        zx=zx if e.Qr is not None else None, lx=lx if e.Qr is not None else None,
                        zu=zu if e.Rr is not None else None, lu=lu if e.Rr is not None else None, solve_mode=e.solve_mode,
-                       active=e.admm_active, seg=self.seg_cols, rec=self.rec, ncol=C_, lin=e.ff_lin(self.rec))
+                       active=e.admm_active, seg=self.seg_cols, rec=self.rec, ncol=C_, lin=e.rec_lin(self.rec, self.seg))
         if self.rec is None:                                    # array form: the factors of the gain pass
             ff.Quu, ff.fac, ff.Qux = e.Quu.data_ptr(), e.fac.data_ptr(), e.Qux.data_ptr()
         if not self._columns_in_one_launch():

@@ -119,11 +119,14 @@ typedef struct isls_gain_args {
                             * steps t = N-1 are not written.  Scratch semantics: the places of trajectories that are
                             * inactive (or past the batch in the last wavefront) are overwritten too, with a copy of
                             * another trajectory's record -- a consumer must use the same `active` mask as this pass   */
-    int32_t lin_on;        /* != 0: A and Bm are what isls_linearize_* wrote for `lin_model` (same contract as isls_ff_args.lin_on).
-                            * ISLS_MODEL_DI: the pass (record forms without Quu / fac / Qux arrays) neither loads nor stages A, Bm
-                            * and evaluates [A B]'V [A B] and A + B K from the two non-zero entries of every column -- the same
-                            * sums in the same order: fp64 results bit-identical to the dense pass, fp32 equal to rounding.  ISLS_MODEL_ARM3R: accepted,
-                            * dense pass.  A hint: every other case runs the dense pass */
+    int32_t lin_on;        /* != 0 (rec given, Quu / fac / Qux NULL; else ISLS_ERR_UNSUPPORTED): A and Bm are what isls_linearize_*
+                            * wrote for `lin_model`.  The records are then written LEAN -- [K | fac | model words] only, at their own
+                            * dense stride in the same buffer -- for feed-forward passes with the same hint (isls_ff_args.lin_on); a
+                            * reader without it would misread them (the entry points that see both blocks check this).
+                            * ISLS_MODEL_DI: the pass also neither loads nor stages A, Bm and evaluates [A B]'V [A B] and A + B K
+                            * from the two non-zero entries of every column -- the same sums in the same order: fp64 results
+                            * bit-identical to the dense pass, fp32 equal to rounding.  ISLS_MODEL_ARM3R (n=9, m=3): dense
+                            * arithmetic, lean records with J = A[6:8,0:3] behind fac.  Other models: ISLS_ERR_UNSUPPORTED */
     int32_t lin_model;
     const void *lin_par;   /* isls_linearize_args.model_par of that model */
     int64_t lin_par_sb;    /* its batch stride in words (0: shared) */
@@ -194,14 +197,15 @@ typedef struct isls_ff_args {
                                      * constraint: notebooks/3DoF robot/State and control bound constraints.ipynb cell 22) is
                                      * then passed with a zero time stride and keeps the one-hand-off record kernel.  Record
                                      * path with time-invariant Qr / Rr only (else ISLS_ERR_UNSUPPORTED: pass the full [N,n,n]) */
-    int32_t lin_on;                 /* != 0 (record path only): A and Bm are what isls_linearize_* wrote for `lin_model`, so the pass may
-                                     * read only the [K | fac (| J)] tail of every record (27 of 81 words at n=6, m=3; 42 of 150 at n=9) and
-                                     * evaluate (A + B K)'v = A'v + K'(B'v) from the model's structure: ISLS_MODEL_DI (A = [I aI; 0 I],
-                                     * B = [b0 I; b1 I]) or ISLS_MODEL_ARM3R (A = [I dtI 0; 0 I 0; J dtJ 0], B = [hI; dtI; hJ], the six
-                                     * words of J = A[6:8,0:3] the gain pass keeps behind fac in the records of the pair (9,3)).  A hint: the records stay complete and the dense form runs where the
-                                     * structured one does not apply (time-varying Qr / Rr); another model is ISLS_ERR_UNSUPPORTED.
-                                     * The same products in another association: results equal up to rounding.  The caller must NOT set
-                                     * it for A, Bm of its own (get_AB callbacks) */
+    int32_t lin_on;                 /* != 0 (record path only): A and Bm are what isls_linearize_* wrote for `lin_model`, and the gain pass
+                                     * that wrote `rec` had the same hint (isls_gain_args.lin_on): the records are LEAN -- only the tail
+                                     * [K | fac | model words] of every record, 28 instead of 82 words per step at n=6, m=3, 42 instead of
+                                     * 150 at n=9 -- and the pass evaluates (A + B K)'v = A'v + K'(B'v) from the model's structure:
+                                     * ISLS_MODEL_DI (A = [I aI; 0 I], B = [b0 I; b1 I]) or ISLS_MODEL_ARM3R (A = [I dtI 0; 0 I 0; J dtJ 0],
+                                     * B = [hI; dtI; hJ], the six words of J = A[6:8,0:3] kept behind fac).  Only the one-hand-off form
+                                     * reads them: time-varying Qr / Rr or a time-parallel `seg` are ISLS_ERR_UNSUPPORTED, another model
+                                     * too.  The same products in another association: results equal up to rounding.  The caller must
+                                     * NOT set it for A, Bm of its own (get_AB callbacks) */
     int32_t lin_model;
     const void *lin_par;            /* isls_linearize_args.model_par of that model */
     int64_t lin_par_sb;             /* batch stride of lin_par in words (0: shared) */

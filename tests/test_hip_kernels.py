@@ -284,14 +284,14 @@ def _di_config(dim, batch, N, seed):
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 1e-4)])
-@pytest.mark.parametrize("ff_nseg", [1, 3])
 @pytest.mark.parametrize("which", ["di1d", "di2d", "di3d_u", "di3d_xu", "arm"])
-def test_model_structured_feedforward(dual, golden, which, ff_nseg, dtype, tol):
-    """isls_ff_args.lin_on: the record pass reads only [K | fac] of every record and evaluates (A + B K)'v = A'v + K'(B'v) from the
-    structure of the model whose linearisation A, B are -- double integrators of dimension 1, 2, 3 (ISLS_MODEL_DI) and the planar
-    arm (ISLS_MODEL_ARM3R, J from A) -- against the oracle's four-term recursion on the dense arrays, whole ADMM traces kernel
-    call by kernel call, sequential and time-parallel, batch sizes that leave wavefront slots empty, both precisions (the arm in
-    fp64 and fp32 at its conditioning-aware bounds, as in the dense-form tests)."""
+def test_model_structured_feedforward(dual, golden, which, dtype, tol, ff_nseg=1):
+    """isls_gain_args.lin_on / isls_ff_args.lin_on: the gain pass writes the lean records [K | fac | model words] and the record
+    pass evaluates (A + B K)'v = A'v + K'(B'v) from the structure of the model whose linearisation A, B are -- double integrators
+    of dimension 1, 2, 3 (ISLS_MODEL_DI) and the planar arm (ISLS_MODEL_ARM3R, J behind fac) -- against the oracle's four-term
+    recursion on the dense arrays, whole ADMM traces kernel call by kernel call, batch sizes that leave wavefront slots empty,
+    both precisions (the arm in fp64 and fp32 at its conditioning-aware bounds, as in the dense-form tests).  Sequential form
+    only: the time-parallel one needs the dense records (test_structured_hint_is_refused_where_it_cannot_apply)."""
     f = np.float64 if dtype == "f64" else np.float32
     if which == "arm":
         g = golden("g4_arm3r.npz")
@@ -316,6 +316,49 @@ def test_model_structured_feedforward(dual, golden, which, ff_nseg, dtype, tol):
     d.run(*steps, 0.0)
     assert dk._rec is not None and dk.lin_calls >= steps[0] * steps[2]   # the structured form really ran
     _report(dk)
+
+
+def test_structured_hint_is_refused_where_it_cannot_apply():
+    """The hint selects the lean record layout, so a pass that cannot honour it must fail instead of falling back: a gain pass
+    asked for the Quu / fac / Qux arrays, a feed-forward pass with time-varying weights or with time-parallel segments, the
+    fused entry with one block hinted and the other not, a model the passes do not know, the array form."""
+    import torch
+    from dual import hip_kernels
+    from isls import models
+    hk = hip_kernels()
+    B, N, n, m = 5, 12, 6, 3
+    A1, B1 = P.double_integrator_AB(3, 2, 0.01)
+    par = torch.as_tensor(np.asarray(models.LTI(A1, B1).params())).cuda()
+    z = lambda *s_: torch.zeros(*s_, dtype=torch.float64, device="cuda")   # noqa: E731
+    A, Bm = z(B, N, n, n), z(B, N, n, m)
+    hk.linearize(capi.MODEL_DI, par, z(B, N, n), z(B, N, m), A, Bm)
+    Cxx, Cuu = torch.eye(n, dtype=torch.float64, device="cuda").expand(B, N, n, n).contiguous(), torch.eye(m, dtype=torch.float64, device="cuda").expand(B, N, m, m).contiguous()
+    K, k, st = z(B, N, m, n), z(B, N, m), torch.zeros(B, dtype=torch.int32, device="cuda")
+    rec = z(capi.ff_record_elems(B, N, n, m))
+    lin = (capi.MODEL_DI, par)
+    G, F = capi.Kernels.gain_args, capi.Kernels.ff_args
+    ok_gain = G(A, Bm, Cxx, Cuu, K, None, None, None, status=st, rec=rec, lin=lin)
+    hk._call("riccati_gain", "f64", ok_gain, None)                 # the valid form runs
+    Rr1, RrN = 0.1 * torch.eye(m, dtype=torch.float64, device="cuda")[None], (0.1 * torch.eye(m, dtype=torch.float64, device="cuda")).expand(N, m, m).contiguous()
+    zu, lu, uh, xh = z(B, N, m), z(B, N, m), z(B, N, m), z(B, N, n)
+    ff_ok = F(A, Bm, z(B, N, n), z(B, N, m), K, None, None, None, k, Rr=Rr1, xhat=xh, uhat=uh, zu=zu, lu=lu, rec=rec, lin=lin)
+    hk._call("riccati_ff", "f64", ff_ok, None)
+    torch.cuda.synchronize()
+    with pytest.raises(capi.IslsError):                            # arrays requested: the dense form would be needed
+        hk._call("riccati_gain", "f64", G(A, Bm, Cxx, Cuu, K, z(B, N, m, m), z(B, N, m, m), z(B, N, m, n), status=st, rec=rec, lin=lin), None)
+    with pytest.raises(capi.IslsError):                            # time-varying weights: not the one-hand-off kernel
+        hk._call("riccati_ff", "f64", F(A, Bm, z(B, N, n), z(B, N, m), K, None, None, None, k, Rr=RrN, xhat=xh, uhat=uh, zu=zu, lu=lu, rec=rec, lin=lin), None)
+    nseg, seg_len = hk.ff_segments(N, 3)
+    seg = capi.Kernels.ff_seg(z(B, N, m, n), z(B, nseg, n, n), z(B, nseg, n), seg_len)
+    with pytest.raises(capi.IslsError):                            # segments: their operators come from the dense records
+        hk._call("riccati_ff", "f64", F(A, Bm, z(B, N, n), z(B, N, m), K, None, None, None, k, Rr=Rr1, xhat=xh, uhat=uh, zu=zu, lu=lu, rec=rec, lin=lin, seg=seg), None)
+    with pytest.raises(capi.IslsError):                            # writer hinted, reader not
+        hk.riccati_gain_ff(ok_gain, F(A, Bm, z(B, N, n), z(B, N, m), K, None, None, None, k, Rr=Rr1, xhat=xh, uhat=uh, zu=zu, lu=lu, rec=rec), "f64")
+    with pytest.raises(capi.IslsError):                            # a model whose structure the passes do not know
+        hk._call("riccati_gain", "f64", G(A, Bm, Cxx, Cuu, K, None, None, None, status=st, rec=rec, lin=(capi.MODEL_CAR, par)), None)
+    with pytest.raises(ValueError):                                # the hint describes records: not the array form
+        F(A, Bm, z(B, N, n), z(B, N, m), K, z(B, N, m, m), z(B, N, m, m), z(B, N, m, n), k, lin=lin)
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("which", ["arm", "car", "tassa"])
@@ -652,7 +695,8 @@ def test_gain_with_first_feedforward_pass(oracle, mode, batch, with_x, dtype, to
 @pytest.mark.parametrize("dim,batch", [(1, 23), (2, 13), (3, 11)])
 def test_structured_gain_pass_is_bit_identical(dim, batch, mode, dtype):
     """isls_gain_args.lin_on (ISLS_MODEL_DI): the gain pass that neither loads nor stages [A B] and takes [A B]'V [A B] and
-    A + B K from the two non-zero entries per column against the dense pass -- K, every written word of the packed records,
+    A + B K from the two non-zero entries per column against the dense pass -- K, every word of the lean records it writes
+    ([K | fac] of every step, against the tail of the dense pass's records),
     and (entry point isls_riccati_gain_ff_*) the first k -- for double integrators of dimension 1, 2, 3, both solve modes, a
     partly filled last wavefront and an inactive trajectory.  fp64: the SAME bits (the terms left out add exact zeros, the
     others keep the dense order).  fp32: equal to rounding only -- the compiler packs some two-term sums of the dense fp32
@@ -707,10 +751,15 @@ def test_structured_gain_pass_is_bit_identical(dim, batch, mode, dtype):
     for fused in (False, True):
         (K0, r0, k0), (K1, r1, k1) = out[(False, fused)], out[(True, fused)]
         assert np.isfinite(K0).all() and np.abs(K0[0]).max() > 0 and np.array_equal(K0[2], np.full_like(K0[2], 7.0))
-        used = n * n + 2 * n * m + m * m                          # words of a record; an odd count is padded by one word nobody writes
-        stride = (used + 1) & ~1
-        r0, r1 = r0.reshape(-1, stride)[:, :used], r1.reshape(-1, stride)[:, :used]
-        assert np.array_equal(np.isnan(r0), np.isnan(r1)) and (~np.isnan(r0)).sum() >= (B - 1) * (N - 1) * used
+        # dense records: [Phi | B | K | fac] at an even stride; with the hint the LEAN ones: their tail [K | fac] at its own even
+        # stride in a prefix of the same buffer (an odd word count is padded by one word nobody writes)
+        used, tail = n * n + 2 * n * m + m * m, m * n + m * m
+        stride, lstride = (used + 1) & ~1, (tail + 1) & ~1
+        nrec = r0.size // stride
+        r0 = r0.reshape(nrec, stride)[:, used - tail:used]
+        assert np.isnan(r1[nrec * lstride:]).all(), "the lean layout wrote past its prefix of the buffer"
+        r1 = r1[:nrec * lstride].reshape(nrec, lstride)[:, :tail]
+        assert np.array_equal(np.isnan(r0), np.isnan(r1)) and (~np.isnan(r0)).sum() >= (B - 1) * (N - 1) * tail
         r0, r1 = np.nan_to_num(r0), np.nan_to_num(r1)
         if dtype == "f64":
             assert np.array_equal(K0, K1), f"K differs (fused={fused}): {np.abs(K0 - K1).max():.3e}"
