@@ -56,18 +56,30 @@ def pmc_tree():
         return None
 
 
-def pmc_traffic(kind):
+# position of the LIN template argument (0: dense form, else a model-structured one) in the kernels that have it
+LIN_ARG = {"riccati_gain_kernel": 8, "riccati_ffrec2_kernel": 6}
+
+
+def pmc_traffic(kind, structured=False):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (tools/pmc_traffic.py),
-    or None when no profile of this workload is available."""
+    or None when no profile of this workload is available.  The profiled run holds both forms of the Riccati passes (the
+    timed region and the general-layout leg): the instances of the form the timed region ran are the ones counted."""
     try:
         kernels = json.load(open(PMC_FILE))["kernels"]
     except (OSError, ValueError, KeyError, TypeError):
         return None
     total, found = 0.0, False
     for name, rec in kernels.items():
-        if "<double" in name and any(("isls::" + k + "<") in name for k in KIND_KERNELS[kind]):
-            total += rec["hbm_bytes"]
-            found = True
+        fam = next((k for k in KIND_KERNELS[kind] if ("isls::" + k + "<") in name), None)
+        if fam is None or "<double" not in name:
+            continue
+        if fam in LIN_ARG:
+            targs = [t.strip() for t in name[name.index("<") + 1:name.rindex(">")].split(",")]
+            lin = targs[LIN_ARG[fam]] if len(targs) > LIN_ARG[fam] else "0"
+            if (lin != "0") != bool(structured):
+                continue
+        total += rec["hbm_bytes"]
+        found = True
     return total if found else None
 
 
@@ -357,7 +369,7 @@ def main():
         for k in range(5):
             avg = fam[k][0] / max(1, fam[k][1])
             ach = abytes[k] * B / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
-            pmc = pmc_traffic(k) if default_workload else None
+            pmc = pmc_traffic(k, structured) if default_workload else None
             families[KIND_NAMES[k]] = {"avg_launch_ms": avg, "algorithmic_bytes_per_launch": abytes[k] * B, "achieved": ach,
                                        "frac": ach / HBM_PEAK_GBS, "pmc_bytes": pmc,
                                        "pmc_over_algorithmic": (pmc / (abytes[k] * B) if pmc and abytes[k] else None)}
@@ -382,7 +394,7 @@ def main():
                        "admm_iterations_per_s": it_per_s * J},
             "roofline": {"bound": "hbm", "kernel": KIND_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(dom) if default_workload else None,
+                         "traffic": pmc_traffic(dom, structured) if default_workload else None,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": abytes[dom] * B,
                          "iteration_algorithmic_bytes": it_bytes,
                          "iteration_frac": it_bytes * (it_per_s / world) / 1e9 / HBM_PEAK_GBS,
