@@ -70,7 +70,14 @@ class ColumnSolver:
         self.rec = e.ff_record()
         self.seg = e.ff_seg()                                   # planned before the gain pass: it decides the records' layout
         inv = lambda W: W is None or W.ndim < 3 or W.shape[-3] == 1                      # noqa: E731
-        e.gain(active=active, rec=self.rec, seg=self.seg, structured=inv(e.Qr) and inv(e.Rr))   # x_step hands e.Qr, e.Rr over as they are
+        structured = inv(e.Qr) and inv(e.Rr)                    # x_step hands e.Qr, e.Rr over as they are
+        if (self.seg is not None and structured and self.C * e.B >= 2048 and "ISLS_FF_NSEG" not in os.environ
+                and e.ff_lin(self.rec, None) is not None):
+            # the C columns of B problems stream like a batch of C B trajectories, and the model-structured form exists for the
+            # sequential recursion only (the segment operators come from the dense records): at 4 x 1024 arm columns the
+            # structured sequential pass takes 83 us, the dense one in four segments 107 us
+            self.seg = None
+        e.gain(active=active, rec=self.rec, seg=self.seg, structured=structured)
         self.seg_cols = None
         if self.seg is not None:
             e.feedforward_prepare(self.seg, active=active, rec=self.rec)
