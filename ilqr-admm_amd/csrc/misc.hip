@@ -214,7 +214,7 @@ __device__ __forceinline__ void linearize_body(const LinP<T> &p, int b, T *tab) 
             T c = T(0), sn[3], cs[3];
             for (int j = 0; j < 3; ++j) {
                 c += x[j] + x[3 + j] * dt + T(0.5) * u[j] * (dt * dt);
-                sn[j] = sin(c); cs[j] = cos(c);
+                sin_cos(c, sn[j], cs[j]);
             }
             for (int j = 0; j < 3; ++j) {
                 T j0 = T(0), j1 = T(0);
@@ -251,13 +251,14 @@ __device__ __forceinline__ void linearize_body(const LinP<T> &p, int b, T *tab) 
         const T d = par[1];
         for (int t = lane; t < N; t += kWave) {
             const T *x = p.xhat + (bN + t) * 4, *u = p.uhat + (bN + t) * 2;
-            const T f = dt * x[3], sw = sin(u[0]), cw = cos(u[0]);
+            T sw, cw;
+            sin_cos(u[0], sw, cw);
+            const T f = dt * x[3];
             const T r = sqrt(d * d - (sw * f) * (sw * f));
             tab[t * 8 + 0] = (f * cw + d) - r;
             tab[t * 8 + 1] = cw + (sw * sw * f) / r;
             tab[t * 8 + 2] = -f * sw + (sw * cw * f * f) / r;
-            tab[t * 8 + 3] = sin(x[2]);
-            tab[t * 8 + 4] = cos(x[2]);
+            sin_cos(x[2], tab[t * 8 + 3], tab[t * 8 + 4]);
             tab[t * 8 + 5] = (cw * f) / r;
             tab[t * 8 + 6] = sw / r;
         }
@@ -288,7 +289,7 @@ __device__ __forceinline__ void linearize_body(const LinP<T> &p, int b, T *tab) 
     // car-simple (Car notebooks cell 6): tab[t] = {sin th, cos th, v, u0}
     for (int t = lane; t < N; t += kWave) {
         const T *x = p.xhat + (bN + t) * 4, *u = p.uhat + (bN + t) * 2;
-        tab[t * 8 + 0] = sin(x[2]); tab[t * 8 + 1] = cos(x[2]); tab[t * 8 + 2] = x[3]; tab[t * 8 + 3] = u[0];
+        sin_cos(x[2], tab[t * 8 + 0], tab[t * 8 + 1]); tab[t * 8 + 2] = x[3]; tab[t * 8 + 3] = u[0];
     }
     __syncthreads();
     for (int e = lane; e < N * 16; e += kWave) {

@@ -74,8 +74,7 @@ struct RoP {
 };
 
 // ---- built-in forward models -------------------------------------------------
-__device__ __forceinline__ void sin_cos(double a, double &s, double &c) { sincos(a, &s, &c); }
-__device__ __forceinline__ void sin_cos(float a, float &s, float &c) { sincosf(a, &s, &c); }
+// sin_cos: isls_common.hpp
 template <typename T, int NX, int NU, int MODEL>
 struct Model;
 
