@@ -222,7 +222,15 @@ __device__ __forceinline__ void sin_cos(float a, float &s, float &c) { sincosf(a
 // (isls_ff_args.lin_on).  The pair (9, 3) carries the six words A[6:8, 0:3] -- the Jacobian rows of ISLS_MODEL_ARM3R, from which
 // its A and B follow -- so that pass reads one contiguous tail [K | fac | J] instead of gathering J from the A array (scattered
 // 8-byte loads at a 64.8 KB stride: the structured form then ran no faster than the dense one).  Other pairs: none.
-__host__ __device__ constexpr int rec_model_words(int n, int m) { return (n == 9 && m == 3) ? 6 : 0; }
+// The pair (4, 2) carries the six entries of ISLS_MODEL_CAR's linearisation that are not 0, 1 or dt: A[0,2], A[1,2], A[0,3],
+// A[1,3], A[2,3], B[2,0] (for the other models of that pair they are copied all the same and nobody reads them).
+__host__ __device__ constexpr int rec_model_words(int n, int m) { return ((n == 9 && m == 3) || (n == 4 && m == 2)) ? 6 : 0; }
+// word e of the model words within one staged step [A_t B_t] (row stride n + m)
+__host__ __device__ constexpr int rec_model_src(int n, int m, int e)
+{
+    return (n == 9) ? (6 + e / 3) * (n + m) + e % 3
+                    : (e == 0 ? 0 * 6 + 2 : e == 1 ? 1 * 6 + 2 : e == 2 ? 0 * 6 + 3 : e == 3 ? 1 * 6 + 3 : e == 4 ? 2 * 6 + 3 : 2 * 6 + 4);
+}
 __host__ __device__ constexpr int rec_stride(int n, int m) { return (n * n + 2 * n * m + m * m + rec_model_words(n, m) + 1) & ~1; }
 // The lean layout (isls_gain_args.lin_on / isls_ff_args.lin_on): only the tail [K | fac | model words] of a record, at this stride
 // (the same buffer: isls_ff_record_elems covers the dense layout, the lean one uses a prefix of it).

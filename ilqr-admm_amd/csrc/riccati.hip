@@ -643,9 +643,13 @@ __global__ __launch_bounds__(64, ISLS_GAIN_OCC) void riccati_gain_kernel(GainP<T
 #pragma unroll
         for (int c = 0; c < NU; ++c) imq[r_b2 + c * r_s2] = tail[c];
         if constexpr (REC && rec_model_words(NX, NU) == 6) {
-            // A[6:8, 0:3] of the step behind fac (rec_model_words): lanes 0..5 of a slot carry one word each, the others word 0 again
+            // the model words of the step behind fac (rec_model_words: the arm's A[6:8, 0:3], the car's six entries): lanes 0..5 of
+            // a slot carry one word each, the others word 0 again
             const int je = i < 6 ? i : 0;
-            imq[s * RW + RFAC + NU * NU + je] = ABs[(6 + je / 3) * W + je % 3];
+            int src = rec_model_src(NX, NU, 0);
+#pragma unroll
+            for (int e = 1; e < 6; ++e) src = (je == e) ? rec_model_src(NX, NU, e) : src;
+            imq[s * RW + RFAC + NU * NU + je] = ABs[src];
         }
         if constexpr (ARR) {
             {
@@ -791,11 +795,12 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     // and Bm are complete, so any other case runs the dense kernel (ISLS_GAIN_LEAN=0 switches the form off)
     if (ff && ff->rec == a.rec && a.rec && (ff->lin_on != 0) != (a.lin_on != 0)) return ISLS_ERR_ARG;   // one layout for writer and reader
     // lin_on also selects the LEAN record layout, which the feed-forward passes of the same hint read: no silent fall-back
-    bool lin_di = false, lean_arm = false;
+    bool lin_di = false, lean_arm = false, lean_car = false;
     if (a.lin_on) {
         if (!a.rec || a.Quu || a.fac || a.Qux) return ISLS_ERR_UNSUPPORTED;        // record form without the arrays only
         if (a.lin_model == ISLS_MODEL_DI) { if (a.n != 2 * a.m || !a.lin_par) return ISLS_ERR_ARG; lin_di = true; }
         else if (a.lin_model == ISLS_MODEL_ARM3R) { if (a.n != 9 || a.m != 3) return ISLS_ERR_ARG; lean_arm = true; }   // dense arithmetic, lean records
+        else if (a.lin_model == ISLS_MODEL_CAR) { if (a.n != 4 || a.m != 2) return ISLS_ERR_ARG; lean_car = true; }     // likewise
         else return ISLS_ERR_UNSUPPORTED;
     }
     p.lin_par = (const T *)a.lin_par; p.lin_par_sb = a.lin_par_sb;
@@ -815,15 +820,19 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_, REC_, ARR_>), dim3(grid), dim3(64), 0, s, p)
 #define LAUNCH_GL(NX_, NU_, MODE_, FF_) \
     hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_, true, false, 1>), dim3(grid), dim3(64), 0, s, p)
+#define LAUNCH_GC(NX_, NU_, MODE_, FF_) /* dense arithmetic, lean records (the car) */      \
+    hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, FF_, true, false, 0, true>), dim3(grid), dim3(64), 0, s, p)
 #define LAUNCH_M(NX_, NU_, MODE_)                                                           \
     {                                                                                       \
         if (with_ff) {                                                                      \
             if constexpr (gain_ff_dims(NX_, NU_)) {                                         \
-                if constexpr (NX_ == 2 * NU_) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, true); else LAUNCH_G(NX_, NU_, MODE_, true, true, false); } \
+                if constexpr (NX_ == 4 && NU_ == 2) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, true); else if (lean_car) LAUNCH_GC(NX_, NU_, MODE_, true); else LAUNCH_G(NX_, NU_, MODE_, true, true, false); } \
+                else if constexpr (NX_ == 2 * NU_) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, true); else LAUNCH_G(NX_, NU_, MODE_, true, true, false); } \
                 else LAUNCH_G(NX_, NU_, MODE_, true, true, false);                          \
             }                                                                               \
         } else if (a.rec && !a.Qux) {                                                       \
-            if constexpr (NX_ == 2 * NU_) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, false); else LAUNCH_G(NX_, NU_, MODE_, false, true, false); } \
+            if constexpr (NX_ == 4 && NU_ == 2) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, false); else if (lean_car) LAUNCH_GC(NX_, NU_, MODE_, false); else LAUNCH_G(NX_, NU_, MODE_, false, true, false); } \
+            else if constexpr (NX_ == 2 * NU_) { if (lin_di) LAUNCH_GL(NX_, NU_, MODE_, false); else LAUNCH_G(NX_, NU_, MODE_, false, true, false); } \
             else if constexpr (NX_ == 9 && NU_ == 3) {                                      \
                 if (lean_arm) hipLaunchKernelGGL((riccati_gain_kernel<T, NX_, NU_, kGainDepth, MODE_, false, true, false, 0, true>), dim3(grid), dim3(64), 0, s, p); \
                 else LAUNCH_G(NX_, NU_, MODE_, false, true, false);                         \
@@ -842,6 +851,7 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     ISLS_DISPATCH_DIMS(a.n, a.m, CALL)
 #undef CALL
 #undef LAUNCH_M
+#undef LAUNCH_GC
 #undef LAUNCH_GL
 #undef LAUNCH_G
     if (did_ff) *did_ff = with_ff;

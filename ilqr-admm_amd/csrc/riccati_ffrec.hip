@@ -270,20 +270,24 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
 //             which the gain pass puts behind fac: rec_model_words):  jv = J'v_ee,  (A'v)_q = v_q + jv,  (A'v)_qd = dt (v_q + jv) + v_qd,  (A'v)_ee = 0,
 //             B'v = h (v_q + jv) + dt v_qd
 // -- the same products as the dense form in another association (results equal up to rounding, same tolerance against the oracle).
-constexpr int LIN_NONE = 0, LIN_DI = 1, LIN_ARM3R = 2;
+//   LIN_CAR   (ISLS_MODEL_CAR):   A = I + {a02, a12, a03, a13, a23}, B = {b20, b31 = dt} (the six entries that vary ride behind
+//             fac):  (A'v)_0 = v_0, (A'v)_1 = v_1, (A'v)_2 = a02 v_0 + a12 v_1 + v_2, (A'v)_3 = a03 v_0 + a13 v_1 + a23 v_2 + v_3,
+//             B'v = (b20 v_2, dt v_3)
+constexpr int LIN_NONE = 0, LIN_DI = 1, LIN_ARM3R = 2, LIN_CAR = 3;
 
 template <typename T, int NX, int NU, int D, int OCC, int MODE, int LIN = LIN_NONE>
 __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
 {
     static_assert(LIN != LIN_DI || NX == 2 * NU, "double integrator: n = 2 d, m = d");
     static_assert(LIN != LIN_ARM3R || (NX == 9 && NU == 3), "planar 3R arm: n = 9, m = 3");
+    static_assert(LIN != LIN_CAR || (NX == 4 && NU == 2), "car: n = 4, m = 2");
     constexpr bool LEAN = LIN != LIN_NONE;
     constexpr int G = NX + NU, W = NX + NU, TPW = kWave / G;
     // the structured forms read the LEAN records the gain pass writes under the same hint: [K | fac | model words] at stride
     // rec_lean_stride; the dense form the whole records at rec_stride
     constexpr int RW = LEAN ? rec_lean_stride(NX, NU) : rec_stride(NX, NU);   // words between the records of consecutive slots in HBM
     constexpr int SRC_OFF = 0;
-    constexpr int NJ = LIN == LIN_ARM3R ? 6 : 0;               // the arm's J behind fac (rec_model_words)
+    constexpr int NJ = (LIN == LIN_ARM3R || LIN == LIN_CAR) ? 6 : 0;   // the model words behind fac the form reads (rec_model_words)
     static_assert(NJ <= rec_model_words(NX, NU), "the records of this pair carry no model words");
     constexpr int SW = RW;                                     // words of a record staged through LDS
     constexpr int PHI_OFF = 0, B_OFF = PHI_OFF + NX * NX, K_OFF = LEAN ? 0 : B_OFF + NX * NU, FAC_OFF = K_OFF + NU * NX;
@@ -359,6 +363,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     T la = T(0), lb0 = T(0), lb1 = T(0), ldt = T(0), lh = T(0);
     if constexpr (LIN == LIN_DI) { la = lpar[0]; lb0 = lpar[1]; lb1 = lpar[2]; }
     if constexpr (LIN == LIN_ARM3R) { ldt = lpar[0]; lh = T(0.5) * (ldt * ldt); }
+    if constexpr (LIN == LIN_CAR) ldt = lpar[0];
     const int lo = LIN == LIN_DI ? ((xl && i >= NU) ? i - NU : 0) : ((xl && i < 6) ? i % 3 : 0);   // the other entry of v the lane needs
     const T sown = LIN == LIN_ARM3R ? ((xl && i < 6) ? T(1) : T(0)) : T(1);
     const T cv = LIN == LIN_DI ? ((xl && i >= NU) ? la : T(0)) : ((xl && i >= 3 && i < 6) ? ldt : T(0));
@@ -487,6 +492,9 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
                 if constexpr (LIN == LIN_DI) {
 #pragma unroll
                     for (int r = 0; r < NU; ++r) w[r] = lb0 * vv[r] + lb1 * vv[NU + r];
+                } else if constexpr (LIN == LIN_CAR) {
+                    w[0] = jm[5] * vv[2];
+                    w[1] = ldt * vv[3];
                 } else {
 #pragma unroll
                     for (int r = 0; r < NU; ++r) {
@@ -495,7 +503,12 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
                         jvo = (lo == r) ? jv : jvo;
                     }
                 }
-                const T atv = (sown * v_own + cv * v_oth) + cj * jvo;      // x-lanes: (A'v)_i
+                T atv = (sown * v_own + cv * v_oth) + cj * jvo;            // x-lanes: (A'v)_i
+                if constexpr (LIN == LIN_CAR) {
+                    const T a2 = (jm[0] * vv[0] + jm[1] * vv[1]) + vv[2];
+                    const T a3 = ((jm[2] * vv[0] + jm[3] * vv[1]) + jm[4] * vv[2]) + vv[3];
+                    atv = (i == 2) ? a2 : ((i == 3) ? a3 : v_own);
+                }
                 T wu = w[0];
 #pragma unroll
                 for (int r = 1; r < NU; ++r) wu = (iu == r) ? w[r] : wu;
@@ -598,6 +611,12 @@ static void launch_ffrec2(int lin, dim3 grid, hipStream_t s, const FfRecP<T> &p)
             return;
         }
     }
+    if constexpr (NX == 4 && NU == 2) {
+        if (lin == LIN_CAR) {
+            hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX, NU, DL, OCC, MODE, LIN_CAR>), grid, dim3(64), 0, s, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((riccati_ffrec2_kernel<T, NX, NU, D, OCC, MODE, LIN_NONE>), grid, dim3(64), 0, s, p);
 }
 
@@ -638,6 +657,7 @@ int launch_ff_record(const isls_ff_args &a, hipStream_t s)
     if (a.lin_on) {
         if (a.lin_model == ISLS_MODEL_DI) { if (a.n != 2 * a.m) return ISLS_ERR_ARG; lin = LIN_DI; }
         else if (a.lin_model == ISLS_MODEL_ARM3R) { if (a.n != 9 || a.m != 3) return ISLS_ERR_ARG; lin = LIN_ARM3R; }
+        else if (a.lin_model == ISLS_MODEL_CAR) { if (a.n != 4 || a.m != 2) return ISLS_ERR_ARG; lin = LIN_CAR; }
         else return ISLS_ERR_UNSUPPORTED;
         if (!a.lin_par) return ISLS_ERR_ARG;
         if (!(rowc && v2_on) || segmented) return ISLS_ERR_UNSUPPORTED;

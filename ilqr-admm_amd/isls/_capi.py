@@ -295,7 +295,7 @@ def _dense(x, shape, name):
 def ff_record_elems(B, N, n, m):
     """isls_ff_record_elems: elements of the packed-record buffer of the gain pass (blocked by wavefront)."""
     tpw = 64 // (n + m)
-    model_words = 6 if (n, m) == (9, 3) else 0                 # rec_model_words (csrc/isls_common.hpp): the arm's A[6:8, 0:3] behind fac
+    model_words = 6 if (n, m) in ((9, 3), (4, 2)) else 0       # rec_model_words (csrc/isls_common.hpp): the arm's A[6:8, 0:3] / the car's six entries behind fac
     return -(-B // tpw) * tpw * N * ((n * n + 2 * n * m + m * m + model_words + 1) & ~1)   # record stride padded to an even word count
 
 

@@ -301,7 +301,7 @@ class Engine:
             return None
         if os.environ.get("ISLS_FF_LEAN", "1") == "0" or os.environ.get("ISLS_FF_V2", "1") == "0":
             return None
-        if self.model not in (capi.MODEL_DI, capi.MODEL_ARM3R) or self.model_par is None:
+        if self.model not in (capi.MODEL_DI, capi.MODEL_ARM3R, capi.MODEL_CAR) or self.model_par is None:
             return None
         if getattr(self, "_ab_made", None) != (self.model, self.A.data_ptr(), self.Bm.data_ptr()):
             return None

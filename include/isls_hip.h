@@ -125,8 +125,8 @@ typedef struct isls_gain_args {
                             * reader without it would misread them (the entry points that see both blocks check this).
                             * ISLS_MODEL_DI: the pass also neither loads nor stages A, Bm and evaluates [A B]'V [A B] and A + B K
                             * from the two non-zero entries of every column -- the same sums in the same order: fp64 results
-                            * bit-identical to the dense pass, fp32 equal to rounding.  ISLS_MODEL_ARM3R (n=9, m=3): dense
-                            * arithmetic, lean records with J = A[6:8,0:3] behind fac.  Other models: ISLS_ERR_UNSUPPORTED */
+                            * bit-identical to the dense pass, fp32 equal to rounding.  ISLS_MODEL_ARM3R (n=9, m=3) and ISLS_MODEL_CAR (n=4, m=2): dense
+                            * arithmetic, lean records with the model words behind fac.  Other models: ISLS_ERR_UNSUPPORTED */
     int32_t lin_model;
     const void *lin_par;   /* isls_linearize_args.model_par of that model */
     int64_t lin_par_sb;    /* its batch stride in words (0: shared) */
@@ -202,7 +202,8 @@ typedef struct isls_ff_args {
                                      * [K | fac | model words] of every record, 28 instead of 82 words per step at n=6, m=3, 42 instead of
                                      * 150 at n=9 -- and the pass evaluates (A + B K)'v = A'v + K'(B'v) from the model's structure:
                                      * ISLS_MODEL_DI (A = [I aI; 0 I], B = [b0 I; b1 I]) or ISLS_MODEL_ARM3R (A = [I dtI 0; 0 I 0; J dtJ 0],
-                                     * B = [hI; dtI; hJ], the six words of J = A[6:8,0:3] kept behind fac).  Only the one-hand-off form
+                                     * B = [hI; dtI; hJ], the six words of J = A[6:8,0:3] kept behind fac) or ISLS_MODEL_CAR (A = I + {a02, a12, a03, a13,
+                                     * a23}, B = {b20, b31 = dt}: those six behind fac).  Only the one-hand-off form
                                      * reads them: time-varying Qr / Rr or a time-parallel `seg` are ISLS_ERR_UNSUPPORTED, another model
                                      * too.  The same products in another association: results equal up to rounding.  The caller must
                                      * NOT set it for A, Bm of its own (get_AB callbacks) */

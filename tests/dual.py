@@ -115,8 +115,8 @@ class DualKernels:
     @staticmethod
     def _lin_hint(model, par, par_dev):
         from isls import models
-        if model == capi.MODEL_ARM3R:
-            return (capi.MODEL_ARM3R, par_dev)
+        if model in (capi.MODEL_ARM3R, capi.MODEL_CAR):
+            return (model, par_dev)
         if model == capi.MODEL_DI:
             return (capi.MODEL_DI, par_dev)
         if model == capi.MODEL_LTI:                            # isls.models.LTI recognises a double integrator in a dense pair

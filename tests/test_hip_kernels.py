@@ -284,11 +284,12 @@ def _di_config(dim, batch, N, seed):
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 1e-4)])
-@pytest.mark.parametrize("which", ["di1d", "di2d", "di3d_u", "di3d_xu", "arm"])
+@pytest.mark.parametrize("which", ["di1d", "di2d", "di3d_u", "di3d_xu", "arm", "car"])
 def test_model_structured_feedforward(dual, golden, which, dtype, tol, ff_nseg=1):
     """isls_gain_args.lin_on / isls_ff_args.lin_on: the gain pass writes the lean records [K | fac | model words] and the record
     pass evaluates (A + B K)'v = A'v + K'(B'v) from the structure of the model whose linearisation A, B are -- double integrators
-    of dimension 1, 2, 3 (ISLS_MODEL_DI) and the planar arm (ISLS_MODEL_ARM3R, J behind fac) -- against the oracle's four-term
+    of dimension 1, 2, 3 (ISLS_MODEL_DI), the planar arm (ISLS_MODEL_ARM3R, J behind fac) and the car (ISLS_MODEL_CAR, its six
+    varying entries behind fac) -- against the oracle's four-term
     recursion on the dense arrays, whole ADMM traces kernel call by kernel call, batch sizes that leave wavefront slots empty,
     both precisions (the arm in fp64 and fp32 at its conditioning-aware bounds, as in the dense-form tests).  Sequential form
     only: the time-parallel one needs the dense records (test_structured_hint_is_refused_where_it_cannot_apply)."""
@@ -300,6 +301,10 @@ def test_model_structured_feedforward(dual, golden, which, dtype, tol, ff_nseg=1
         tol = max(1e-10, 10 * float(np.max(g["o2_sens"]))) if dtype == "f64" else max(1e-4, 10 * amp * 2.0 ** -24)
         pa, kw = problem_arrays(cfg, range(7), dtype=f), dict(rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
         steps = (2, cfg["max_line_search"], 4)
+    elif which == "car":                                           # ISLS_MODEL_CAR: the six varying entries of A, B behind fac, N = 200
+        cfg = P.config4(batch=16, N=200, seed=0)
+        pa, kw = problem_arrays(cfg, range(13), dtype=f), dict(rho_x=cfg["rho_x"], rho_u=cfg["rho_u"], project_x=True)
+        steps = (2, 20, 3)
     else:
         dim = {"di1d": 1, "di2d": 2}.get(which, 3)
         cfg = _di_config(dim, batch=40, N=100, seed=5)
@@ -311,7 +316,7 @@ def test_model_structured_feedforward(dual, golden, which, dtype, tol, ff_nseg=1
             kw = dict(rho_x=0.05, rho_u=cfg["rho_u"], project_x=True, relax=1.5)
         steps = (2, 20, 4)
     dk = dual(tol=tol, ff_nseg=ff_nseg, ff_record=True, ti_weights=True, ff_lin=True)
-    dk.int_exact = dtype == "f64" and which != "arm"               # near-ties of the arg-min may flip in fp32 / on the arm
+    dk.int_exact = dtype == "f64" and which not in ("arm", "car")  # near-ties of the arg-min may flip in fp32 / on the arm / the car
     d = OracleDriver(dk, pa, dtype=f, **kw)
     d.run(*steps, 0.0)
     assert dk._rec is not None and dk.lin_calls >= steps[0] * steps[2]   # the structured form really ran
@@ -754,7 +759,8 @@ def test_structured_gain_pass_is_bit_identical(dim, batch, mode, dtype):
         # dense records: [Phi | B | K | fac] at an even stride; with the hint the LEAN ones: their tail [K | fac] at its own even
         # stride in a prefix of the same buffer (an odd word count is padded by one word nobody writes)
         used, tail = n * n + 2 * n * m + m * m, m * n + m * m
-        stride, lstride = (used + 1) & ~1, (tail + 1) & ~1
+        mw = 6 if (n, m) == (4, 2) else 0                          # model words of the pair (rec_model_words): behind fac in both layouts
+        stride, lstride = (used + mw + 1) & ~1, (tail + mw + 1) & ~1
         nrec = r0.size // stride
         r0 = r0.reshape(nrec, stride)[:, used - tail:used]
         assert np.isnan(r1[nrec * lstride:]).all(), "the lean layout wrote past its prefix of the buffer"
