@@ -59,7 +59,19 @@ static int outer_iteration(const isls_outer_args &a, hipStream_t s)
         {
             ScopedTimer tm(tmg, 0, s);
             static const bool fuse_ff = [] { const char *e = getenv("ISLS_GAIN_FF"); return !e || atoi(e) != 0; }();
-            if ((rc = launch_gain<T>(a.gain, s, (fuse_ff && a.J > 0) ? &a.ff : nullptr, &ff_done)) != ISLS_OK) return rc;
+            // The gain pass with the recursion inside holds 370-400 registers: one wavefront per SIMD.  While its wavefronts fit
+            // the chip's SIMDs that costs nothing; beyond (B > 7168 at n = 6, m = 3 on 256 CUs) the surplus runs as a second round
+            // and the launch doubles (123 -> 251 us from B = 4096 to 8192), where the pass without the recursion (<= 256 registers,
+            // two wavefronts per SIMD) and a feed-forward launch of its own take 148 + 82 us.
+            static const int64_t simds = [] {
+                int dev = 0; hipDeviceProp_t pr;
+                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return (int64_t)1024;
+                return (int64_t)pr.multiProcessorCount * 4;
+            }();
+            const int lanes = a.gain.n + a.gain.m;
+            const int64_t waves = lanes > 0 && lanes <= kWave ? (a.gain.B + kWave / lanes - 1) / (kWave / lanes) : 0;
+            const bool fuse_now = fuse_ff && a.J > 0 && waves <= simds;
+            if ((rc = launch_gain<T>(a.gain, s, fuse_now ? &a.ff : nullptr, &ff_done)) != ISLS_OK) return rc;
         }
         if (ff_seg_enabled(a.ff.seg)) {                        // operators of the time-parallel feed-forward pass
             const isls_ff_args &f = a.ff;
