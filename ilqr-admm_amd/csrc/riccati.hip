@@ -791,8 +791,8 @@ int launch_gain(const isls_gain_args &a, hipStream_t s, const isls_ff_args *ff, 
     p.xhat = p.uhat = p.zx = p.lx = p.zu = p.lu = nullptr; p.kff = nullptr;
     static const int rev_mode = [] { const char *e = getenv("ISLS_GAIN_REV"); return e ? atoi(e) : 0; }();   // EXPERIMENT
     p.rev = rev_mode ? 1 : 0;
-    // model-structured form (isls_gain_args.lin_on): the double integrator, on the record forms the drivers use; a hint -- A
-    // and Bm are complete, so any other case runs the dense kernel (ISLS_GAIN_LEAN=0 switches the form off)
+    // model-structured form (isls_gain_args.lin_on): on the record forms the drivers use; the caller switches it off by not
+    // giving the hint (isls.Engine: use_model_structure / ISLS_FF_LEAN=0, for the gain pass and its readers together)
     if (ff && ff->rec == a.rec && a.rec && (ff->lin_on != 0) != (a.lin_on != 0)) return ISLS_ERR_ARG;   // one layout for writer and reader
     // lin_on also selects the LEAN record layout, which the feed-forward passes of the same hint read: no silent fall-back
     bool lin_di = false, lean_arm = false, lean_car = false;
