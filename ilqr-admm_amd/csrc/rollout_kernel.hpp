@@ -184,6 +184,13 @@ struct Model<T, 4, 2, ISLS_MODEL_TASSA> {      // Tassa car-parking [x, y, theta
 #ifndef ISLS_RO_SW
 #define ISLS_RO_SW 16
 #endif
+#ifndef ISLS_RO_HOIST_WR
+#define ISLS_RO_HOIST_WR 0
+#endif
+// EXPERIMENT (off): the augmented-Lagrangian operands of the u block read with the step's first batch of LDS reads instead of
+// behind `if (has_wr)` -- one exposed LDS round trip per step less, 12 registers more: the two-wavefront form of n = 6, m = 3
+// reaches 256 registers and spills 64 B, line search 70.2 -> 72.2 us, outer iteration +15-20 us (tools/kbench.py, same box)
+constexpr bool kHoistWr = ISLS_RO_HOIST_WR != 0;
 constexpr int kRolloutDepth = 2;   // steps of record words in flight per lane (D = 2..5 ran within 3 %: issue bound; 2 is leanest)
 constexpr int kMaxSeg = 16;        // winner replay: at most this many segments
 
@@ -675,12 +682,17 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
         }                                                                                                                   \
         /* u = (x - xhat) K' + alpha k + uhat            (isls.py:328-329) */                                               \
         T u[NU];                                                                                                            \
+        T rru_h[LY::even(NU)], rwr_h[LY::even(NU)];           /* kHoistWr: the AL operands of the u block ride in the first batch */ \
         {                                                                                                                   \
             T rK[LY::even(NU * NX)], rxh[LY::even(NX)], rk[LY::even(NU)], ruh[LY::even(NU)];                                \
             ro_read<W>(rec + O_K, rK);                                                                                      \
             ro_read<W>(rec + O_XH, rxh);                                                                                    \
             ro_read<W>(rec + O_KK, rk);                                                                                     \
             ro_read<W>(rec + O_UH, ruh);                                                                                    \
+            if constexpr (kHoistWr) {                                                                                       \
+                ro_read<W>(rec + O_RU, rru_h);                                                                              \
+                ro_read<W>(rec + O_WR, rwr_h);                                                                              \
+            }                                                                                                               \
             _Pragma("unroll") for (int r = 0; r < NU; ++r) {                                                                \
                 T acc = T(0);                                                                                               \
                 _Pragma("unroll") for (int j = 0; j < NX; ++j) acc += (x[j] - rxh[j]) * rK[r * NX + j];                     \
@@ -731,11 +743,13 @@ __global__ __launch_bounds__(64, OCC) void rollout_kernel(RoP<T> p)
         }                                                                                                                   \
         if (has_wr) {                                                                                                       \
             T rru[LY::even(NU)], rwr[LY::even(NU)];                                                                         \
-            ro_read<W>(rec + O_RU, rru);                                                                                    \
-            ro_read<W>(rec + O_WR, rwr);                                                                                    \
+            if constexpr (!kHoistWr) {                                                                                      \
+                ro_read<W>(rec + O_RU, rru);                                                                                \
+                ro_read<W>(rec + O_WR, rwr);                                                                                \
+            }                                                                                                               \
             _Pragma("unroll") for (int r = 0; r < NU; ++r) {                                                                \
-                const T df = u[r] - rru[r];                                                                                 \
-                ag1 += (df * df) * rwr[r];                                                                                  \
+                const T df = u[r] - (kHoistWr ? rru_h[r] : rru[r]);                                                         \
+                ag1 += (df * df) * (kHoistWr ? rwr_h[r] : rwr[r]);                                                          \
             }                                                                                                               \
         }                                                                                                                   \
         if (TAILF) {                                          /* dead (padding) steps leave the sums alone */               \
