@@ -261,18 +261,19 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec_kernel(FfRecP<T> p)
 //   * every memory instruction is unconditional (lanes without a regularised block load c0 again, surplus lanes repeat the
 //     last lane, slots without a trajectory shadow the first valid one, every lane of a slot stores an entry of k_t), so
 //     the compiler's vmcnt bookkeeping stays exact and D steps of records really are in flight.
-// The sums are those of riccati_ffrec_kernel in the same order: results are bit-identical to it.
+// The sums of the dense form (LIN = 0) are those of riccati_ffrec_kernel in the same order: its results are bit-identical to it.
 // LIN (isls_ff_args.lin_on): 0 = the whole record, Phi'v from its [Phi | B] block.  Otherwise A and B are the linearisation of a
-// built-in model whose structure the pass knows, so it reads only the [K | fac] tail of every record (27 of 81 words at n = 6,
-// m = 3; 42 of 150 at n = 9, J included) and evaluates  Phi'v = A'v + K'(B'v)  with
+// built-in model whose structure the pass knows, the records are the LEAN ones the gain pass wrote under the same hint
+// ([K | fac | model words] at stride rec_lean_stride: 28 instead of 82 words per step at n = 6, m = 3; 42 instead of 150 at
+// n = 9) and the pass evaluates  Phi'v = A'v + K'(B'v)  with
 //   LIN_DI    (ISLS_MODEL_DI):    A = [I aI; 0 I], B = [b0 I; b1 I]:  (A'v)_i = v_i (+ a v_{i-d}),  (B'v)_r = b0 v_r + b1 v_{d+r}
 //   LIN_ARM3R (ISLS_MODEL_ARM3R): A = [I dtI 0; 0 I 0; J dtJ 0], B = [hI; dtI; hJ], h = dt^2/2, J = A[6:8, 0:3] (6 words per step,
 //             which the gain pass puts behind fac: rec_model_words):  jv = J'v_ee,  (A'v)_q = v_q + jv,  (A'v)_qd = dt (v_q + jv) + v_qd,  (A'v)_ee = 0,
 //             B'v = h (v_q + jv) + dt v_qd
-// -- the same products as the dense form in another association (results equal up to rounding, same tolerance against the oracle).
 //   LIN_CAR   (ISLS_MODEL_CAR):   A = I + {a02, a12, a03, a13, a23}, B = {b20, b31 = dt} (the six entries that vary ride behind
 //             fac):  (A'v)_0 = v_0, (A'v)_1 = v_1, (A'v)_2 = a02 v_0 + a12 v_1 + v_2, (A'v)_3 = a03 v_0 + a13 v_1 + a23 v_2 + v_3,
 //             B'v = (b20 v_2, dt v_3)
+// -- the same products as the dense form in another association (results equal up to rounding, same tolerance against the oracle).
 constexpr int LIN_NONE = 0, LIN_DI = 1, LIN_ARM3R = 2, LIN_CAR = 3;
 
 template <typename T, int NX, int NU, int D, int OCC, int MODE, int LIN = LIN_NONE>
@@ -286,7 +287,6 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     // the structured forms read the LEAN records the gain pass writes under the same hint: [K | fac | model words] at stride
     // rec_lean_stride; the dense form the whole records at rec_stride
     constexpr int RW = LEAN ? rec_lean_stride(NX, NU) : rec_stride(NX, NU);   // words between the records of consecutive slots in HBM
-    constexpr int SRC_OFF = 0;
     constexpr int NJ = (LIN == LIN_ARM3R || LIN == LIN_CAR) ? 6 : 0;   // the model words behind fac the form reads (rec_model_words)
     static_assert(NJ <= rec_model_words(NX, NU), "the records of this pair carry no model words");
     constexpr int SW = RW;                                     // words of a record staged through LDS
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64, OCC) void riccati_ffrec2_kernel(FfRecP<T> p)
     for (int j = 0; j < JR; ++j) {
         const int q = lane + kWave * j;
         const int w = 2 * (q < NP ? q : NP - 1);               // word within the staged words of the wavefront's slots
-        oR[j] = (uint32_t)((w / SW) * RW + SRC_OFF + (w % SW));
+        oR[j] = (uint32_t)w;                                   // (SW == RW in both layouts: the staged words are the record)
         dR[j] = q < NP ? (w / SW) * SLOT + (w % SW) : TPW * SLOT + DUMP_OFF;
     }
     // where this lane READS its slot's record: its own slot, or the shadowed one
