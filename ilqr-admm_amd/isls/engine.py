@@ -271,12 +271,14 @@ class Engine:
     # linearisation (isls_ff_args.lin_on), never for a caller's A, B
     def _mark_ab_made(self):
         self._ab_made = (self.model, self.A.data_ptr(), self.Bm.data_ptr())
+        self._ab_caller = False
 
     def ab_from_caller(self):
         """A, Bm were written by somebody else (AB setter, get_AB callback): the dense records are the only valid form.
         A cached isls_outer_args block keeps its pointers; run_outer() rewrites its hint fields when this state has changed."""
         self._ab_made = None
         self._ab_static = None
+        self._ab_caller = True
 
     def _ab_is_static(self):
         """A, Bm hold the one linearisation of a state-independent model, written for every trajectory"""
@@ -289,6 +291,19 @@ class Engine:
         for a in blocks:
             capi.Kernels._set_lin(a, lin, self.B, self.dtype)
         return lin
+
+    def _structure_expected(self):
+        """Will the passes of this engine get the model hint, as far as can be told before A, B are linearised: a model whose
+        structure the passes know, no A, B handed in by a caller, the forms not switched off, time-invariant weights."""
+        if not self.fast_dims or not getattr(self, "use_model_structure", True) or getattr(self, "_ab_caller", False):
+            return False
+        if os.environ.get("ISLS_FF_LEAN", "1") == "0" or os.environ.get("ISLS_FF_V2", "1") == "0" or os.environ.get("ISLS_FF_RECORD", "1") == "0":
+            return False
+        if self.model not in (capi.MODEL_DI, capi.MODEL_ARM3R, capi.MODEL_CAR):
+            return False
+        inv = lambda W: W is None or W.ndim < 3 or W.shape[-3] == 1       # noqa: E731
+        Qr_ok = inv(self.Qr) or getattr(self, "Qr_term", None) is not None
+        return inv(self.Rr) and Qr_ok
 
     def ff_lin(self, rec, seg=None):
         """(model id, parameters) for isls_gain_args.lin_on / isls_ff_args.lin_on, or None.  The hint makes the gain pass write
@@ -420,8 +435,11 @@ class Engine:
             # shape (82-87 us for 1, 2 or 3 segments at B=4096; 45 / 36+29 / 39+26 us pass+prepare at B=2048), so the
             # sequential recursion wins: no operators to prepare per gain pass, no stitch launch per ADMM iteration.
             # Smaller batches are bound by the N dependent steps and keep the time-parallel form (B=512: 42 us sequential,
-            # 30 us in four segments).
-            nseg_requested = int(os.environ.get("ISLS_FF_NSEG", "1" if self.B >= 2048 else "4"))
+            # 30 us in four segments).  Where the model-structured passes apply (ff_lin) they exist for the sequential
+            # recursion only and carry the cheaper gain pass with them: outer iteration at n=6, m=3 (tools/kbench.py, one box)
+            # B=256: 504 us segmented / 511 us structured, 512: 517 / 510, 1024: 553 / 535, 1536: 608 / 559 -- sequential from 512.
+            seq_from = 512 if self._structure_expected() else 2048
+            nseg_requested = int(os.environ.get("ISLS_FF_NSEG", "1" if self.B >= seq_from else "4"))
         nseg, seg_len = self.kern.ff_segments(self.N, nseg_requested)
         if nseg < 2:
             return None

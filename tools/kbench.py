@@ -46,7 +46,7 @@ def run(args):
         return e0.elapsed_time(e1) / reps * 1e3               # us
 
     out = {}
-    out["gain"] = timed(lambda: eng.gain(active=act, rec=rec), args.reps)
+    out["gain"] = timed(lambda: eng.gain(active=act, rec=rec, seg=seg), args.reps)
     out["ff"] = timed(lambda: eng.feedforward(active=act, seg=seg, rec=rec), args.reps)
     out["prep"] = timed(lambda: eng.feedforward_prepare(seg, active=act, rec=rec), args.reps) if seg is not None else 0.0
     out["rollout"] = timed(lambda: eng.rollout(L, active=act), args.reps)
