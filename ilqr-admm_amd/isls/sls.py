@@ -59,6 +59,7 @@ class SLS(Base):
         e = self.engine
         e.set_model(self._model.model_id, self._model.params())
         e.A, e.Bm = e._t(self.A).reshape(1, 1, self.x_dim, self.x_dim), e._t(self.B).reshape(1, 1, self.x_dim, self.u_dim)
+        e.ab_from_caller()                                      # a shared pair installed as it is: the dense passes, their plan
 
     def forward_model(self, x, u):
         return self._model(np.asarray(x), np.asarray(u))
