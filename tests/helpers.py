@@ -246,14 +246,18 @@ def tassa_arrays(g, bsel, dtype=np.float64):
     return d
 
 
-def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.0, dtype="f64", outer_iters=1, scramble_best=None):
+def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.0, dtype="f64", outer_iters=1, scramble_best=None,
+                              structured=False):
     """One outer DP-form iLQR-ADMM iteration through the library's own driver (`isls_ilqr_admm_outer_*`: gain pass with the
     first feed-forward pass inside, J x [ff -> rollout with the fused ADMM update]) on the device, and the same through the
     oracle's driver on the host; returns the worst relative error over K, k, the x-step, z, lambda and the residuals.
     dtype "f64" / "f32" selects isls_ilqr_admm_outer_f64 / _f32 (and the oracle of the same precision); outer_iters > 1 repeats
     the iteration (linearise + expand, driver call, accept) so that the gain pass also sees a moved nominal.  scramble_best (a
     seed): the `best` array the rollout reads as its PREDICTION of the winner is filled with random candidate indices first, so
-    that wavefronts with mispredicted, correctly predicted and mixed winners all occur (recorded winner vs replay)."""
+    that wavefronts with mispredicted, correctly predicted and mixed winners all occur (recorded winner vs replay).
+    structured: the gain pass and the feed-forward passes get the model hint isls.Engine gives them for this workload
+    (isls_gain_args.lin_on / isls_ff_args.lin_on: the linearisation is a double integrator's): lean records, the Riccati passes
+    on the model's structure -- against the same oracle run on the dense arrays."""
     import torch
     f = np.float64 if dtype == "f64" else np.float32
     o = OracleDriver(oracle_kern, problem_arrays(cfg, bsel, dtype=f), rho_u=rho_u, relax=relax, dtype=f)
@@ -268,9 +272,15 @@ def outer_iteration_on_device(cfg, bsel, hip, oracle_kern, L, J, rho_u, relax=1.
     rec = torch.zeros(capi.ff_record_elems(B, N, n, m), dtype=torch.float64 if dtype == "f64" else torch.float32, device="cuda")
     pa, K = h.pa, capi.Kernels
     alphas = torch.from_numpy(ALPHAS[:L].astype(f)).cuda()
-    gain = K.gain_args(h.A, h.Bm, h.Cxx, h.Cuu, h.K, None, None, None, status=h.status, active=h.admm_active, rec=rec)
+    lin = None
+    if structured:
+        from dual import DualKernels
+        lin = DualKernels._lin_hint(pa["model"], np.asarray(problem_arrays(cfg, bsel, dtype=f)["model_par"]), pa["model_par"])
+        assert lin is not None, "this workload has no model-structured form"
+        h._lin_par = lin[1]                                    # the argument blocks hold its address
+    gain = K.gain_args(h.A, h.Bm, h.Cxx, h.Cuu, h.K, None, None, None, status=h.status, active=h.admm_active, rec=rec, lin=lin)
     ff = K.ff_args(h.A, h.Bm, h.c0x, h.c0u, h.K, None, None, None, h.k, Rr=h.Rr[:1], xhat=h.xhat, uhat=h.uhat, zu=h.zu, lu=h.lu,
-                   active=h.admm_active, rec=rec)
+                   active=h.admm_active, rec=rec, lin=lin)
     ro = K.rollout_args(pa["model"], pa["model_par"], h.K, h.k, h.xhat, h.uhat, alphas, pa["Qtab"], pa["ztab"], pa["seq"],
                         pa["u_std"], h.xx, h.xu, best=h.best, cost_new=h.cost_new, wr=h.wr[:1], zu=h.zu, lu=h.lu, cost_cur=h.cost,
                         status=h.status, active=h.admm_active)

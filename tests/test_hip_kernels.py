@@ -855,16 +855,20 @@ def test_short_horizons_through_the_record_path(dual, N):
     assert err < 1e-10, f"N={N}: {err:.2e}"
 
 
+@pytest.mark.parametrize("structured", [False, True])
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 1e-4)])
 @pytest.mark.parametrize("B,J,L", [(33, 3, 20), (8, 5, 7)])
-def test_outer_driver_both_precisions(oracle, B, J, L, dtype, tol):
+def test_outer_driver_both_precisions(oracle, B, J, L, dtype, tol, structured):
     """isls_ilqr_admm_outer_f64 / _f32 as bench.py runs it (gain pass with the first feed-forward pass inside, record
     feed-forward passes on time-invariant weights, ADMM updates fused into the rollout) over two outer iterations against the
-    oracle's own driver of the same precision: K, k, the x-step, z, lambda, residuals, the accepted nominal and its cost."""
+    oracle's own driver of the same precision: K, k, the x-step, z, lambda, residuals, the accepted nominal and its cost.
+    structured: with the model hint bench.py's engine gives (the Riccati passes on the double integrator's structure, lean
+    records) -- the timed region's form; without: the general layout."""
     from dual import hip_kernels
     from helpers import outer_iteration_on_device
     cfg = P.config2(batch=B, N=100, seed=7)
-    err = outer_iteration_on_device(cfg, range(B), hip_kernels(), oracle, L, J, cfg["rho_u"], cfg["relax"], dtype=dtype, outer_iters=2)
+    err = outer_iteration_on_device(cfg, range(B), hip_kernels(), oracle, L, J, cfg["rho_u"], cfg["relax"], dtype=dtype, outer_iters=2,
+                                    structured=structured)
     assert err < tol, f"{dtype}: {err:.2e}"
 
 

@@ -2,8 +2,8 @@
 """Randomised parity sweep (not part of the test suite: run once after kernel changes): the outer driver on the device
 (gain + first feed-forward pass in one launch, record feed-forward passes, roll-outs with the fused ADMM update) against
 the oracle's driver for random batch sizes, horizons, candidate counts and ADMM iteration counts of the double-integrator
-workload (config 2) in one to three dimensions.
-    python tools/random_sweep.py [--cases 60] [--seed 0]
+workload (config 2).
+    python tools/random_sweep.py [--cases 60] [--seed 0] [--structured] [--max-batch 48]
 Prints the worst relative deviation over all cases; exits non-zero above 1e-9."""
 import argparse
 import os
@@ -24,13 +24,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--structured", action="store_true",
+                    help="the Riccati passes with the model hint isls.Engine gives this workload (lean records, the double integrator's "
+                         "structure): bench.py's timed region; default: the dense passes of the general layout")
+    ap.add_argument("--max-batch", type=int, default=48)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     hip = hip_kernels()
     okern, _ = orc.load()
     worst, worst_case = 0.0, None
     for c in range(a.cases):
-        B = int(rng.integers(1, 48))
+        B = int(rng.integers(1, a.max_batch))
         N = int(rng.integers(2, 70))
         L = int(rng.choice([1, 2, 3, 5, 8, 12, 20, 24, 33]))
         J = int(rng.integers(1, 5))
@@ -38,7 +42,7 @@ def main():
         cfg = P.config2(batch=B, N=N, seed=seed)
         # every other case starts from a scrambled prediction of the line-search winner (recorded winner vs replay, mixed wavefronts)
         err = outer_iteration_on_device(cfg, range(B), hip, okern, L, J, cfg["rho_u"], cfg["relax"], outer_iters=1 + c % 2,
-                                        scramble_best=(seed if c % 2 else None))
+                                        scramble_best=(seed if c % 2 else None), structured=a.structured)
         print(f"case {c:3d}: B={B:3d} N={N:3d} L={L:2d} J={J} seed={seed:3d}  err {err:.2e}", flush=True)
         if not (err <= worst):
             worst, worst_case = err, (B, N, L, J, seed)
